@@ -1,0 +1,165 @@
+/*
+ * lutr.h -- C-ABI of the MI355X-native 3D-LUT apply engine (liblutr.so).
+ *
+ * This is the drop-in boundary for ONE path of ionlz/LUT-renderer: the per-pixel
+ * work the reference delegates to the external `ffmpeg` process through the
+ * filter string it builds at
+ *     src/lut_renderer/ffmpeg.py:246   lut3d=file='<cube>':interp=<mode>
+ * together with the conversions it (or ffmpeg's filter negotiation) puts around
+ * that filter:
+ *     src/lut_renderer/ffmpeg.py:212-236   scale=in_range=..:out_range=..:in_color_matrix=..
+ *     src/lut_renderer/ffmpeg.py:224,233   format=<8-bit intermediate>
+ *     src/lut_renderer/ffmpeg.py:304-310   format=<pix_fmt>
+ * The reference has no FFI for this path (it spawns a process,
+ * src/lut_renderer/task_manager.py:145-151); these entry points are what a
+ * ctypes binding would load instead (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures
+ *     (a HIP stream crosses as void*).
+ *   - every function returns 0 on success or a negative errno-style code;
+ *     lutr_last_error() returns a thread-local message for the last failure.
+ *   - pixel-plane pointers handed to lutr_apply_* are DEVICE pointers on the
+ *     context's GPU.  The library never falls back to the CPU: with no usable
+ *     GPU, lutr_ctx_create fails with LUTR_EIO.
+ *   - the caller owns every buffer it passes; the library owns the context,
+ *     its stream (unless one is injected) and the device copy of the lattice.
+ *   - a context is not shared between threads; different contexts are independent.
+ */
+#ifndef LUTR_H
+#define LUTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LUTR_VERSION_STRING "0.1.0"
+
+/* error codes (negative errno values; mirrors FFmpeg's AVERROR(EINVAL) / AVERROR_INVALIDDATA split) */
+#define LUTR_OK        0
+#define LUTR_ENOENT   (-2)    /* file not found */
+#define LUTR_EIO      (-5)    /* HIP runtime failure / no GPU */
+#define LUTR_ENOMEM   (-12)
+#define LUTR_EINVAL   (-22)   /* bad argument, unsupported format, LUT_3D_SIZE outside [2,256] */
+#define LUTR_EILSEQ   (-84)   /* malformed .cube ("invalid data"), unexpected EOF */
+
+/* interpolation, numbered like FFmpeg's lut3d `interp` option values
+ * (replaces the interp= half of ffmpeg.py:242-246) */
+enum lutr_interp {
+    LUTR_INTERP_NEAREST     = 0,
+    LUTR_INTERP_TRILINEAR   = 1,
+    LUTR_INTERP_TETRAHEDRAL = 2,
+    LUTR_INTERP_PYRAMID     = 3,
+    LUTR_INTERP_PRISM       = 4
+};
+
+/* YUV<->RGB matrices the reference can name (ffmpeg.py:119-125) */
+enum lutr_matrix {
+    LUTR_MATRIX_BT709  = 0,
+    LUTR_MATRIX_BT601  = 1,   /* smpte170m and bt470bg */
+    LUTR_MATRIX_BT2020 = 2    /* bt2020nc; bt2020c uses the same coefficients */
+};
+
+/* ranges (in_range=/out_range= at ffmpeg.py:225) */
+enum lutr_range { LUTR_RANGE_TV = 0, LUTR_RANGE_PC = 1 };
+
+/* planar YUV formats: depth | csx<<8 | csy<<9  (csx/csy = log2 chroma subsampling) */
+#define LUTR_FMT(depth, csx, csy) ((depth) | ((csx) << 8) | ((csy) << 9))
+#define LUTR_FMT_DEPTH(f) ((f) & 0xff)
+#define LUTR_FMT_CSX(f)   (((f) >> 8) & 1)
+#define LUTR_FMT_CSY(f)   (((f) >> 9) & 1)
+#define LUTR_FMT_YUV420P     LUTR_FMT(8, 1, 1)
+#define LUTR_FMT_YUV422P     LUTR_FMT(8, 1, 0)
+#define LUTR_FMT_YUV444P     LUTR_FMT(8, 0, 0)
+#define LUTR_FMT_YUV420P10   LUTR_FMT(10, 1, 1)
+#define LUTR_FMT_YUV422P10   LUTR_FMT(10, 1, 0)
+#define LUTR_FMT_YUV444P10   LUTR_FMT(10, 0, 0)
+#define LUTR_FMT_YUV420P12   LUTR_FMT(12, 1, 1)
+#define LUTR_FMT_YUV422P12   LUTR_FMT(12, 1, 0)
+#define LUTR_FMT_YUV444P12   LUTR_FMT(12, 0, 0)
+
+/* What the filter chain around lut3d does to a YUV frame (ffmpeg.py:212-236, :304-310).
+ *   src codes (fmt_in, range_src)
+ *     -> optional prologue to (lut_depth, range_in)       scale=in_range=pc:out_range=..,format=yuv4xxp
+ *     -> integer RGB at lut_depth via matrix_in           (auto-inserted scaler ahead of lut3d)
+ *     -> lut3d                                            ffmpeg.py:246
+ *     -> YUV (fmt_out, range_out) via matrix_out          format=<pix_fmt>, ffmpeg.py:309
+ * The prologue runs iff range_src != range_in or depth(fmt_in) != lut_depth.
+ * fmt_in and fmt_out must have the same chroma subsampling. */
+typedef struct lutr_yuv_params {
+    int32_t fmt_in;
+    int32_t fmt_out;
+    int32_t lut_depth;
+    int32_t matrix_in;
+    int32_t matrix_out;
+    int32_t range_src;
+    int32_t range_in;
+    int32_t range_out;
+} lutr_yuv_params;
+
+/* One frame (or a batch of equally laid out frames) of three planes.
+ * stride = bytes between rows; frame_stride = bytes between consecutive frames of
+ * a batch (ignored when nframes == 1).  Planar RGB uses FFmpeg's gbrp order
+ * (plane 0 = G, 1 = B, 2 = R); YUV uses Y, Cb, Cr. */
+typedef struct lutr_planes {
+    void     *data[3];
+    ptrdiff_t stride[3];
+    int64_t   frame_stride[3];
+} lutr_planes;
+
+typedef struct lutr_ctx lutr_ctx;
+
+const char *lutr_version(void);
+const char *lutr_last_error(void);
+
+/* ---- .cube files (host side; what lut3d's file= option does, ffmpeg.py:246) ---- */
+/* Parses `path` with FFmpeg's parse_cube semantics.  On success *rgb is a malloc'ed
+ * n*n*n*3 float lattice indexed ((r*n+g)*n+b)*3+c (blue fastest), scale[c] =
+ * clip(1/(DOMAIN_MAX[c]-DOMAIN_MIN[c]), 0, 1).  Free with lutr_cube_free. */
+int  lutr_cube_parse(const char *path, float **rgb, int *n, float scale[3]);
+void lutr_cube_free(float *rgb);
+
+/* ---- context ---- */
+int  lutr_ctx_create(int device, lutr_ctx **out);
+void lutr_ctx_destroy(lutr_ctx *ctx);
+/* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the context's own stream */
+int  lutr_ctx_set_stream(lutr_ctx *ctx, void *hip_stream);
+int  lutr_ctx_sync(lutr_ctx *ctx);
+
+/* upload a host lattice (layout of lutr_cube_parse) */
+int  lutr_ctx_set_lut(lutr_ctx *ctx, const float *rgb, int n, const float scale[3]);
+/* multi-GPU: a non-root rank allocates the device lattice without filling it, the host
+ * broadcasts into the pointer returned by lutr_ctx_lut_device (RCCL, root = the rank that
+ * called lutr_ctx_set_lut), then every rank may apply. */
+int  lutr_ctx_lut_alloc(lutr_ctx *ctx, int n, const float scale[3]);
+int  lutr_ctx_lut_device(lutr_ctx *ctx, void **dptr, size_t *bytes);
+/* bytes of the device lattice layout for size n: (n+1)^3 nodes of 16 bytes */
+size_t lutr_lattice_bytes(int n);
+
+/* ---- apply (device pointers; asynchronous on the context's stream) ---- */
+/* lut3d on planar RGB at `depth` bits (8 -> uint8 planes, 9..16 -> uint16 LE planes),
+ * luma rows [row0, row0+rows) of each of nframes frames. */
+int lutr_apply_planar_rgb(lutr_ctx *ctx, int depth, int interp, int w, int h, int nframes,
+                          const lutr_planes *src, const lutr_planes *dst, int row0, int rows);
+
+/* fused YUV -> RGB -> lut3d -> RGB -> YUV; row0 and rows must be multiples of the
+ * chroma block height (2 for 4:2:0) unless row0+rows == h. */
+int lutr_apply_yuv(lutr_ctx *ctx, const lutr_yuv_params *p, int interp, int w, int h, int nframes,
+                   const lutr_planes *src, const lutr_planes *dst, int row0, int rows);
+
+/* ---- tuning / introspection (bench and tests) ---- */
+/* kernel variant: 0 = auto, 1 = generic (scalar, any layout), 2 = vector + global gather,
+ * 3 = vector + LDS lattice window */
+int lutr_ctx_set_variant(lutr_ctx *ctx, int variant);
+/* name of the kernel variant the last apply call launched ("" before the first) */
+const char *lutr_ctx_last_kernel(lutr_ctx *ctx);
+/* the constant block the YUV kernels use, for cross-checking against the oracle: 32 floats */
+int lutr_yuv_constants(const lutr_yuv_params *p, float out[32]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUTR_H */

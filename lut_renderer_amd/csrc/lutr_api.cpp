@@ -1,0 +1,422 @@
+// lutr_api.cpp -- C-ABI layer of liblutr.so: contexts, lattice upload, argument
+// checking, and the YUV constant block.  Kernels live in lutr_kernels.hip.
+//
+// Boundary being replaced: the reference spawns `ffmpeg ... -vf ...lut3d=...` per task
+// (/root/reference/src/lut_renderer/task_manager.py:145-151 with the argv from
+// ffmpeg.py:179-414); include/lutr.h lists which filter-string fragment each entry
+// point stands in for.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lutr_internal.h"
+
+namespace lutr {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+static int hip_fail(hipError_t e, const char *what)
+{
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return LUTR_EIO;
+}
+
+#define HIP_TRY(call) \
+    do { \
+        hipError_t e_ = (call); \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+// ---------------------------------------------------------------- YUV constants
+static bool matrix_k(int m, double *kr, double *kb)
+{
+    switch (m) {
+    case LUTR_MATRIX_BT709:  *kr = 0.2126; *kb = 0.0722; return true;
+    case LUTR_MATRIX_BT601:  *kr = 0.299;  *kb = 0.114;  return true;
+    case LUTR_MATRIX_BT2020: *kr = 0.2627; *kb = 0.0593; return true;
+    }
+    return false;
+}
+
+// DESIGN.md "YUV contract".  All coefficients are formed in double and rounded to
+// float once; the kernels then use exactly these floats.
+int make_yuv_consts(const lutr_yuv_params &p, YuvConsts *o)
+{
+    const int din = LUTR_FMT_DEPTH(p.fmt_in), dout = LUTR_FMT_DEPTH(p.fmt_out), dl = p.lut_depth;
+    if (din < 8 || din > 16 || dout < 8 || dout > 16 || dl < 8 || dl > 16) {
+        set_error("unsupported bit depth (in %d, lut %d, out %d)", din, dl, dout);
+        return LUTR_EINVAL;
+    }
+    if (LUTR_FMT_CSX(p.fmt_in) != LUTR_FMT_CSX(p.fmt_out) || LUTR_FMT_CSY(p.fmt_in) != LUTR_FMT_CSY(p.fmt_out)) {
+        set_error("fmt_in and fmt_out must share chroma subsampling");
+        return LUTR_EINVAL;
+    }
+    if (LUTR_FMT_CSX(p.fmt_in) == 0 && LUTR_FMT_CSY(p.fmt_in) == 1) {
+        set_error("4:4:0 chroma layout is not supported");
+        return LUTR_EINVAL;
+    }
+    auto range_ok = [](int r) { return r == LUTR_RANGE_TV || r == LUTR_RANGE_PC; };
+    if (!range_ok(p.range_src) || !range_ok(p.range_in) || !range_ok(p.range_out)) {
+        set_error("bad range value");
+        return LUTR_EINVAL;
+    }
+    const bool prologue = (p.range_src != p.range_in) || (din != dl);
+    if (prologue && p.range_src != LUTR_RANGE_PC) {
+        // the reference only emits the prologue for full-range sources (ffmpeg.py:129-134, :212)
+        set_error("a range/depth prologue is only defined for full-range (pc) sources");
+        return LUTR_EINVAL;
+    }
+    double kr, kb;
+    if (!matrix_k(p.matrix_in, &kr, &kb)) {
+        set_error("bad matrix_in %d", p.matrix_in);
+        return LUTR_EINVAL;
+    }
+    std::memset(o, 0, sizeof(*o));
+    const int chroma_n = 1 << (LUTR_FMT_CSX(p.fmt_in) + LUTR_FMT_CSY(p.fmt_in));
+
+    if (prologue) {
+        const double mi = (double)((1 << din) - 1);
+        const double sl = (double)(1 << (dl - 8));
+        const double ml = (double)((1 << dl) - 1);
+        const double half_in = (double)(1 << (din - 1));
+        double py, pyo, pc, pco;
+        if (p.range_in == LUTR_RANGE_TV) {
+            py = 219.0 * sl / mi;  pyo = 16.0 * sl;
+            pc = 224.0 * sl / mi;  pco = 128.0 * sl - half_in * pc;
+        } else {
+            py = ml / mi;          pyo = 0.0;
+            pc = ml / mi;          pco = 128.0 * sl - half_in * pc;
+        }
+        o->pre = 1.0f;
+        o->py = (float)py;  o->pyb = (float)(pyo + 0.5);
+        o->pc = (float)pc;  o->pcb = (float)(pco + 0.5);
+        o->pre_max = (float)ml;
+    }
+    {
+        const double kg = 1.0 - kr - kb;
+        const double s = (double)(1 << (dl - 8));
+        const double m = (double)((1 << dl) - 1);
+        double ky, yoff, kc;
+        if (p.range_in == LUTR_RANGE_TV) { ky = m / (219.0 * s); yoff = 16.0 * s; kc = m / (224.0 * s); }
+        else { ky = 1.0; yoff = 0.0; kc = 1.0; }
+        o->ky = (float)ky;
+        o->yb = (float)(-ky * yoff + 0.5);
+        o->coff = (float)(128.0 * s);
+        o->krv = (float)(2.0 * (1.0 - kr) * kc);
+        o->kbu = (float)(2.0 * (1.0 - kb) * kc);
+        o->kgu = (float)(-2.0 * kb * (1.0 - kb) / kg * kc);
+        o->kgv = (float)(-2.0 * kr * (1.0 - kr) / kg * kc);
+        o->max_l = (float)m;
+    }
+    if (!matrix_k(p.matrix_out, &kr, &kb)) {
+        set_error("bad matrix_out %d", p.matrix_out);
+        return LUTR_EINVAL;
+    }
+    {
+        const double kg = 1.0 - kr - kb;
+        const double so = (double)(1 << (dout - 8));
+        const double mo = (double)((1 << dout) - 1);
+        const double ml = (double)((1 << dl) - 1);
+        const double n = (double)chroma_n;
+        double ys, yoff, cs;
+        if (p.range_out == LUTR_RANGE_TV) { ys = 219.0 * so; yoff = 16.0 * so; cs = 224.0 * so; }
+        else { ys = mo; yoff = 0.0; cs = mo; }
+        o->cyr = (float)(ys * kr / ml);
+        o->cyg = (float)(ys * kg / ml);
+        o->cyb = (float)(ys * kb / ml);
+        o->yob = (float)(yoff + 0.5);
+        o->cbr = (float)(cs * (-kr / (2.0 * (1.0 - kb))) / ml / n);
+        o->cbg = (float)(cs * (-kg / (2.0 * (1.0 - kb))) / ml / n);
+        o->cbb = (float)(cs * 0.5 / ml / n);
+        o->crr = (float)(cs * 0.5 / ml / n);
+        o->crg = (float)(cs * (-kg / (2.0 * (1.0 - kr))) / ml / n);
+        o->crb = (float)(cs * (-kb / (2.0 * (1.0 - kr))) / ml / n);
+        o->cob = (float)(128.0 * so + 0.5);
+        o->max_o = (float)mo;
+    }
+    return LUTR_OK;
+}
+
+}  // namespace lutr
+
+using namespace lutr;
+
+struct lutr_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    float4 *lat = nullptr;
+    size_t lat_bytes = 0;
+    int n = 0;
+    float scale[3] = {1.f, 1.f, 1.f};
+    int variant = VAR_AUTO;
+    std::string last_kernel;
+};
+
+extern "C" {
+
+const char *lutr_version(void) { return LUTR_VERSION_STRING; }
+const char *lutr_last_error(void) { return g_last_error.c_str(); }
+
+size_t lutr_lattice_bytes(int n)
+{
+    if (n < 2 || n > 256) return 0;
+    const size_t n1 = (size_t)n + 1;
+    return n1 * n1 * n1 * sizeof(float4);
+}
+
+int lutr_yuv_constants(const lutr_yuv_params *p, float out[32])
+{
+    if (!p || !out) {
+        set_error("lutr_yuv_constants: null argument");
+        return LUTR_EINVAL;
+    }
+    YuvConsts k;
+    const int rc = make_yuv_consts(*p, &k);
+    if (rc) return rc;
+    std::memcpy(out, &k, sizeof(k));
+    return LUTR_OK;
+}
+
+int lutr_ctx_create(int device, lutr_ctx **out)
+{
+    if (!out) {
+        set_error("lutr_ctx_create: null out pointer");
+        return LUTR_EINVAL;
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); liblutr has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return LUTR_EIO;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (have %d)", device, count);
+        return LUTR_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(device));
+    lutr_ctx *c = new lutr_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return hip_fail(e, "hipStreamCreateWithFlags");
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return LUTR_OK;
+}
+
+void lutr_ctx_destroy(lutr_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->lat) (void)hipFree(c->lat);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int lutr_ctx_set_stream(lutr_ctx *c, void *hip_stream)
+{
+    if (!c) { set_error("null context"); return LUTR_EINVAL; }
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return LUTR_OK;
+}
+
+int lutr_ctx_sync(lutr_ctx *c)
+{
+    if (!c) { set_error("null context"); return LUTR_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LUTR_OK;
+}
+
+int lutr_ctx_set_variant(lutr_ctx *c, int variant)
+{
+    if (!c || variant < VAR_AUTO || variant > VAR_VEC_LDS) {
+        set_error("bad variant %d", variant);
+        return LUTR_EINVAL;
+    }
+    c->variant = variant;
+    return LUTR_OK;
+}
+
+const char *lutr_ctx_last_kernel(lutr_ctx *c) { return c ? c->last_kernel.c_str() : ""; }
+
+static int alloc_lattice(lutr_ctx *c, int n, const float scale[3])
+{
+    if (!c || !scale) { set_error("null argument"); return LUTR_EINVAL; }
+    if (n < 2 || n > 256) {
+        set_error("too large or invalid 3D LUT size %d", n);
+        return LUTR_EINVAL;
+    }
+    for (int i = 0; i < 3; i++)
+        if (!(scale[i] >= 0.f && scale[i] <= 1.f)) {
+            set_error("scale[%d] = %g outside [0,1]", i, (double)scale[i]);
+            return LUTR_EINVAL;
+        }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = lutr_lattice_bytes(n);
+    if (bytes != c->lat_bytes) {
+        if (c->lat) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->lat); c->lat = nullptr; c->lat_bytes = 0; }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return LUTR_ENOMEM; }
+        c->lat = (float4 *)p;
+        c->lat_bytes = bytes;
+    }
+    c->n = n;
+    std::memcpy(c->scale, scale, sizeof(c->scale));
+    return LUTR_OK;
+}
+
+int lutr_ctx_lut_alloc(lutr_ctx *c, int n, const float scale[3]) { return alloc_lattice(c, n, scale); }
+
+int lutr_ctx_set_lut(lutr_ctx *c, const float *rgb, int n, const float scale[3])
+{
+    if (!rgb) { set_error("null lattice"); return LUTR_EINVAL; }
+    const size_t count = (size_t)(n > 0 ? n : 0) * n * n * 3;
+    for (size_t i = 0; i < count && n >= 2 && n <= 256; i++)
+        if (!std::isfinite(rgb[i])) {
+            set_error("non-finite lattice value at float %zu", i);
+            return LUTR_EINVAL;
+        }
+    const int rc = alloc_lattice(c, n, scale);
+    if (rc) return rc;
+    // pack [r][g][b][3] -> (n+1)^3 float4 with the last node replicated on each axis
+    const int n1 = n + 1;
+    std::vector<float4> host((size_t)n1 * n1 * n1);
+    for (int r = 0; r < n1; r++) {
+        const int rr = r < n ? r : n - 1;
+        for (int g = 0; g < n1; g++) {
+            const int gg = g < n ? g : n - 1;
+            for (int b = 0; b < n1; b++) {
+                const int bb = b < n ? b : n - 1;
+                const float *s = &rgb[(((size_t)rr * n + gg) * n + bb) * 3];
+                host[((size_t)r * n1 + g) * n1 + b] = make_float4(s[0], s[1], s[2], 0.f);
+            }
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->lat, host.data(), c->lat_bytes, hipMemcpyHostToDevice));
+    return LUTR_OK;
+}
+
+int lutr_ctx_lut_device(lutr_ctx *c, void **dptr, size_t *bytes)
+{
+    if (!c || !dptr || !bytes) { set_error("null argument"); return LUTR_EINVAL; }
+    if (!c->lat) { set_error("no lattice set on this context"); return LUTR_EINVAL; }
+    *dptr = c->lat;
+    *bytes = c->lat_bytes;
+    return LUTR_OK;
+}
+
+static int check_common(lutr_ctx *c, int interp, int w, int h, int nframes, const lutr_planes *src,
+                        const lutr_planes *dst, int row0, int rows)
+{
+    if (!c || !src || !dst) { set_error("null argument"); return LUTR_EINVAL; }
+    if (!c->lat) { set_error("no lattice set on this context (call lutr_ctx_set_lut first)"); return LUTR_EINVAL; }
+    if (interp < LUTR_INTERP_NEAREST || interp > LUTR_INTERP_PRISM) {
+        set_error("unknown interpolation mode %d", interp);
+        return LUTR_EINVAL;
+    }
+    if (w < 0 || h < 0 || nframes < 0 || row0 < 0 || rows < 0 || row0 + rows > h) {
+        set_error("bad geometry w=%d h=%d nframes=%d row0=%d rows=%d", w, h, nframes, row0, rows);
+        return LUTR_EINVAL;
+    }
+    return LUTR_OK;
+}
+
+static void fill_planes(PlaneSet *P, const lutr_planes *src, const lutr_planes *dst)
+{
+    for (int i = 0; i < 3; i++) {
+        P->s[i] = (const uint8_t *)src->data[i];
+        P->d[i] = (uint8_t *)dst->data[i];
+        P->ss[i] = src->stride[i];
+        P->ds[i] = dst->stride[i];
+        P->sfs[i] = src->frame_stride[i];
+        P->dfs[i] = dst->frame_stride[i];
+    }
+}
+
+static void fill_lut(LutConsts *L, const lutr_ctx *c, int depth)
+{
+    const int maxi = (1 << depth) - 1;
+    L->lat = c->lat;
+    L->n1 = c->n + 1;
+    L->maxf = (float)maxi;
+    L->scale_f = 1.0f / (float)maxi;
+    L->lut_max = (float)(c->n - 1);
+    for (int i = 0; i < 3; i++) L->sc[i] = c->scale[i] * L->lut_max;
+}
+
+static int finish_launch(lutr_ctx *c, const char *name)
+{
+    if (!name) {
+        set_error("the requested kernel variant cannot take this layout (alignment, width multiple, depth mix or mode)");
+        return LUTR_EINVAL;
+    }
+    c->last_kernel = name;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, name);
+    return LUTR_OK;
+}
+
+int lutr_apply_planar_rgb(lutr_ctx *c, int depth, int interp, int w, int h, int nframes,
+                          const lutr_planes *src, const lutr_planes *dst, int row0, int rows)
+{
+    int rc = check_common(c, interp, w, h, nframes, src, dst, row0, rows);
+    if (rc) return rc;
+    if (depth < 8 || depth > 16) { set_error("unsupported depth %d", depth); return LUTR_EINVAL; }
+    if (w == 0 || rows == 0 || nframes == 0) return LUTR_OK;
+    for (int i = 0; i < 3; i++)
+        if (!src->data[i] || !dst->data[i]) { set_error("null plane %d", i); return LUTR_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    LutConsts L; PlaneSet P; FrameGeom G{w, h, row0, rows, nframes};
+    fill_lut(&L, c, depth);
+    fill_planes(&P, src, dst);
+    return finish_launch(c, launch_rgb(c->stream, c->variant, L, P, G, depth, interp));
+}
+
+int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int h, int nframes,
+                   const lutr_planes *src, const lutr_planes *dst, int row0, int rows)
+{
+    int rc = check_common(c, interp, w, h, nframes, src, dst, row0, rows);
+    if (rc) return rc;
+    if (!p) { set_error("null yuv params"); return LUTR_EINVAL; }
+    YuvConsts K;
+    rc = make_yuv_consts(*p, &K);
+    if (rc) return rc;
+    const int csx = LUTR_FMT_CSX(p->fmt_in), csy = LUTR_FMT_CSY(p->fmt_in);
+    const int bh = 1 << csy;
+    if (row0 % bh || (rows % bh && row0 + rows != h)) {
+        set_error("row0/rows must be multiples of the chroma block height %d", bh);
+        return LUTR_EINVAL;
+    }
+    if (w == 0 || rows == 0 || nframes == 0) return LUTR_OK;
+    for (int i = 0; i < 3; i++)
+        if (!src->data[i] || !dst->data[i]) { set_error("null plane %d", i); return LUTR_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    LutConsts L; PlaneSet P; FrameGeom G{w, h, row0, rows, nframes};
+    fill_lut(&L, c, p->lut_depth);
+    fill_planes(&P, src, dst);
+    return finish_launch(c, launch_yuv(c->stream, c->variant, L, K, P, G, LUTR_FMT_DEPTH(p->fmt_in),
+                                       LUTR_FMT_DEPTH(p->fmt_out), csx, csy, interp));
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// lutr_internal.h -- structures shared by the C-ABI layer (lutr_api.cpp) and the
+// gfx950 kernels (lutr_kernels.hip).  Not part of the public boundary.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lutr.h"
+
+namespace lutr {
+
+// Device lattice: (n+1)^3 nodes of float4 {r,g,b,0}, index ((r*n1+g)*n1+b), blue
+// fastest like FFmpeg's lut[r*N*N + g*N + b].  Index n on every axis
+// is a replica of node n-1, so NEXT(x) = min(prev+1, n-1) (A.4) becomes prev+1 with
+// no clamp in the kernels.
+struct LutConsts {
+    const float4 *lat;
+    int   n1;            // n + 1
+    float scale_f;       // 1.0f / (2^depth - 1)
+    float sc[3];         // scale.{r,g,b} * (n-1)
+    float lut_max;       // (float)(n-1)
+    float maxf;          // (float)(2^depth - 1)
+};
+
+// Constant block of the YUV contract; same fields, same order as the
+// oracle's orc_yuv_consts so tests can compare them float for float.
+struct YuvConsts {
+    float ky, yb, coff, krv, kgu, kgv, kbu, max_l;
+    float cyr, cyg, cyb, yob;
+    float cbr, cbg, cbb;
+    float crr, crg, crb, cob;
+    float max_o;
+    float pre;                       // 0 or 1
+    float py, pyb, pc, pcb, pre_max;
+    float pad[6];                    // -> 32 floats
+};
+static_assert(sizeof(YuvConsts) == 32 * sizeof(float), "YuvConsts is the 32-float block of lutr_yuv_constants");
+
+struct PlaneSet {
+    const uint8_t *s[3];
+    uint8_t       *d[3];
+    long long ss[3], ds[3];          // row strides, bytes
+    long long sfs[3], dfs[3];        // frame strides, bytes
+};
+
+struct FrameGeom {
+    int w, h, row0, rows, nframes;
+};
+
+enum Variant { VAR_AUTO = 0, VAR_GENERIC = 1, VAR_VEC_GLOBAL = 2, VAR_VEC_LDS = 3 };
+
+// launchers (lutr_kernels.hip); return the kernel's name, or nullptr when the variant
+// cannot take this layout (caller then falls back to the generic kernel)
+const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const PlaneSet &P,
+                       const FrameGeom &G, int depth, int interp);
+const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const YuvConsts &K,
+                       const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy,
+                       int interp);
+
+// host helpers (yuv_consts.cpp / cube_parse.cpp)
+int make_yuv_consts(const lutr_yuv_params &p, YuvConsts *out);
+void set_error(const char *fmt, ...);
+
+}  // namespace lutr

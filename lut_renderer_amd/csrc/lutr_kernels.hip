@@ -1,0 +1,525 @@
+// lutr_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the 3D-LUT apply engine.
+//
+// What they replace: the per-pixel loops of FFmpeg's lut3d filter (and the scalers
+// around it) that the reference invokes through
+//   /root/reference/src/lut_renderer/ffmpeg.py:246   lut3d=file=...:interp=...
+//   /root/reference/src/lut_renderer/ffmpeg.py:212-236, :304-310  scale= / format=
+// Semantics: SURVEY.md Appendix A (lut3d) and DESIGN.md "YUV contract".
+//
+// Compiled with -ffp-contract=off: every product and sum of the lut3d restatement
+// rounds separately, in FFmpeg's scalar C order, so results are bit-identical to the
+// CPU oracle.  Fused multiply-adds appear only where written as __builtin_fmaf.
+//
+// This is gather + lerp: no MFMA.  The bound is HBM (6 B/px for yuv420p10le in+out)
+// and, before that, VALU issue; see DESIGN.md "Kernels".
+#include "lutr_internal.h"
+
+namespace lutr {
+
+// ---------------------------------------------------------------- small math
+__device__ __forceinline__ float med3(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float min3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// ---------------------------------------------------------------- lattice access
+// Global-memory gather (served by L1 / the XCD's L2: a 33^3 padded lattice is 629 KB).
+struct GFetch {
+    const float4 *__restrict__ lat;
+    float fr, fg;   // node strides as floats: n1*n1, n1 (blue stride is 1)
+    int   sr, sg;   // the same as ints
+    __device__ __forceinline__ explicit GFetch(const LutConsts &L)
+        : lat(L.lat), fr((float)(L.n1 * L.n1)), fg((float)L.n1), sr(L.n1 * L.n1), sg(L.n1) {}
+    // exact: all three terms are integers below 2^24 (n1 <= 257)
+    __device__ __forceinline__ int index(float pr, float pg, float pb) const
+    {
+        return (int)fma_(pr, fr, fma_(pg, fg, pb));
+    }
+    __device__ __forceinline__ float4 ld(int i) const { return lat[i]; }
+};
+
+// ---------------------------------------------------------------- lut3d core
+struct Rgb { float r, g, b; };
+
+__device__ __forceinline__ float lerpf(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
+
+template <class F>
+__device__ __forceinline__ Rgb interp_nearest(const F &f, float sr, float sg, float sb)
+{
+    const float4 c = f.ld(f.index(floorf(sr + .5f), floorf(sg + .5f), floorf(sb + .5f)));
+    return Rgb{c.x, c.y, c.z};
+}
+
+template <class F>
+__device__ __forceinline__ Rgb interp_trilinear(const F &f, float sr, float sg, float sb)
+{
+    const float pr = floorf(sr), pg = floorf(sg), pb = floorf(sb);
+    const float dr = sr - pr, dg = sg - pg, db = sb - pb;
+    const int i = f.index(pr, pg, pb);
+    const float4 c000 = f.ld(i), c001 = f.ld(i + 1);
+    const float4 c010 = f.ld(i + f.sg), c011 = f.ld(i + f.sg + 1);
+    const float4 c100 = f.ld(i + f.sr), c101 = f.ld(i + f.sr + 1);
+    const float4 c110 = f.ld(i + f.sr + f.sg), c111 = f.ld(i + f.sr + f.sg + 1);
+    Rgb o;
+#define TRI(ch) \
+    { \
+        const float c00 = lerpf(c000.ch, c100.ch, dr), c10 = lerpf(c010.ch, c110.ch, dr); \
+        const float c01 = lerpf(c001.ch, c101.ch, dr), c11 = lerpf(c011.ch, c111.ch, dr); \
+        const float c0 = lerpf(c00, c10, dg), c1 = lerpf(c01, c11, dg); \
+        o_ = lerpf(c0, c1, db); \
+    }
+    float o_;
+    TRI(x) o.r = o_;
+    TRI(y) o.g = o_;
+    TRI(z) o.b = o_;
+#undef TRI
+    return o;
+}
+
+// FFmpeg's six branches all evaluate (1-x)*c000 + (x-y)*cA + (y-z)*cB + z*c111 with
+// (x,y,z) = (d.r,d.g,d.b) sorted descending, cA one step along x's axis and cB one more
+// along y's.  Ties only change a tap whose weight is exactly 0, so for a finite lattice
+// the max3/med3/min3 form below is bit-identical to the branchy original.
+template <class F>
+__device__ __forceinline__ Rgb interp_tetrahedral(const F &f, float sr, float sg, float sb)
+{
+    const float pr = floorf(sr), pg = floorf(sg), pb = floorf(sb);
+    const float dr = sr - pr, dg = sg - pg, db = sb - pb;
+    const int i = f.index(pr, pg, pb);
+    const float x = max3(dr, dg, db), y = med3(dr, dg, db), z = min3(dr, dg, db);
+    const int oa = (dr == x) ? f.sr : ((dg == x) ? f.sg : 1);
+    const int oz = (db == z) ? 1 : ((dg == z) ? f.sg : f.sr);
+    const int o111 = f.sr + f.sg + 1;
+    const float4 c0 = f.ld(i), c1 = f.ld(i + oa), c2 = f.ld(i + o111 - oz), c3 = f.ld(i + o111);
+    const float w0 = 1.0f - x, w1 = x - y, w2 = y - z, w3 = z;
+    Rgb o;
+    o.r = w0 * c0.x + w1 * c1.x + w2 * c2.x + w3 * c3.x;
+    o.g = w0 * c0.y + w1 * c1.y + w2 * c2.y + w3 * c3.y;
+    o.b = w0 * c0.z + w1 * c1.z + w2 * c2.z + w3 * c3.z;
+    return o;
+}
+
+// pyramid / prism (generic kernel only)
+template <class F>
+__device__ Rgb interp_pyramid(const F &f, float sr, float sg, float sb)
+{
+    const float pr = floorf(sr), pg = floorf(sg), pb = floorf(sb);
+    const float dr = sr - pr, dg = sg - pg, db = sb - pb;
+    const int i = f.index(pr, pg, pb);
+    const float4 c000 = f.ld(i), c001 = f.ld(i + 1);
+    const float4 c010 = f.ld(i + f.sg), c011 = f.ld(i + f.sg + 1);
+    const float4 c100 = f.ld(i + f.sr), c101 = f.ld(i + f.sr + 1);
+    const float4 c110 = f.ld(i + f.sr + f.sg), c111 = f.ld(i + f.sr + f.sg + 1);
+    Rgb o;
+#define PYR(ch, out) \
+    if (dg > dr && db > dr) { \
+        out = c000.ch + (c111.ch - c011.ch) * dr + (c010.ch - c000.ch) * dg + (c001.ch - c000.ch) * db + \
+              (c011.ch - c001.ch - c010.ch + c000.ch) * dg * db; \
+    } else if (dr > dg && db > dg) { \
+        out = c000.ch + (c100.ch - c000.ch) * dr + (c111.ch - c101.ch) * dg + (c001.ch - c000.ch) * db + \
+              (c101.ch - c001.ch - c100.ch + c000.ch) * dr * db; \
+    } else { \
+        out = c000.ch + (c100.ch - c000.ch) * dr + (c010.ch - c000.ch) * dg + (c111.ch - c110.ch) * db + \
+              (c110.ch - c100.ch - c010.ch + c000.ch) * dr * dg; \
+    }
+    PYR(x, o.r) PYR(y, o.g) PYR(z, o.b)
+#undef PYR
+    return o;
+}
+
+template <class F>
+__device__ Rgb interp_prism(const F &f, float sr, float sg, float sb)
+{
+    const float pr = floorf(sr), pg = floorf(sg), pb = floorf(sb);
+    const float dr = sr - pr, dg = sg - pg, db = sb - pb;
+    const int i = f.index(pr, pg, pb);
+    const float4 c000 = f.ld(i), c001 = f.ld(i + 1);
+    const float4 c010 = f.ld(i + f.sg), c011 = f.ld(i + f.sg + 1);
+    const float4 c100 = f.ld(i + f.sr), c101 = f.ld(i + f.sr + 1);
+    const float4 c110 = f.ld(i + f.sr + f.sg), c111 = f.ld(i + f.sr + f.sg + 1);
+    Rgb o;
+#define PRI(ch, out) \
+    if (db > dr) { \
+        out = c000.ch + (c001.ch - c000.ch) * db + (c101.ch - c001.ch) * dr + (c010.ch - c000.ch) * dg + \
+              (c000.ch - c010.ch - c001.ch + c011.ch) * db * dg + \
+              (c001.ch - c011.ch - c101.ch + c111.ch) * dr * dg; \
+    } else { \
+        out = c000.ch + (c101.ch - c100.ch) * db + (c100.ch - c000.ch) * dr + (c010.ch - c000.ch) * dg + \
+              (c100.ch - c110.ch - c101.ch + c111.ch) * db * dg + \
+              (c000.ch - c010.ch - c100.ch + c110.ch) * dr * dg; \
+    }
+    PRI(x, o.r) PRI(y, o.g) PRI(z, o.b)
+#undef PRI
+    return o;
+}
+
+template <int INTERP, class F>
+__device__ __forceinline__ Rgb interp(const F &f, float sr, float sg, float sb)
+{
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) return interp_nearest(f, sr, sg, sb);
+    else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) return interp_trilinear(f, sr, sg, sb);
+    else if constexpr (INTERP == LUTR_INTERP_PYRAMID) return interp_pyramid(f, sr, sg, sb);
+    else if constexpr (INTERP == LUTR_INTERP_PRISM) return interp_prism(f, sr, sg, sb);
+    else return interp_tetrahedral(f, sr, sg, sb);
+}
+
+// One pixel of A.3.  In: integer codes held as floats.  Out: integer codes held as
+// floats (truncation toward zero, then clip to [0, M], exactly av_clip_uintp2((int)(v*M))).
+template <int INTERP, class F>
+__device__ __forceinline__ Rgb lut3d_px(const LutConsts &L, const F &f, float rc, float gc, float bc)
+{
+    const float xr = rc * L.scale_f, xg = gc * L.scale_f, xb = bc * L.scale_f;
+    const float sr = med3(xr * L.sc[0], 0.0f, L.lut_max);
+    const float sg = med3(xg * L.sc[1], 0.0f, L.lut_max);
+    const float sb = med3(xb * L.sc[2], 0.0f, L.lut_max);
+    const Rgb v = interp<INTERP>(f, sr, sg, sb);
+    Rgb o;
+    o.r = med3(truncf(v.r * L.maxf), 0.0f, L.maxf);
+    o.g = med3(truncf(v.g * L.maxf), 0.0f, L.maxf);
+    o.b = med3(truncf(v.b * L.maxf), 0.0f, L.maxf);
+    return o;
+}
+
+template <class F>
+__device__ __forceinline__ Rgb lut3d_px_rt(int mode, const LutConsts &L, const F &f, float r, float g, float b)
+{
+    switch (mode) {
+    case LUTR_INTERP_NEAREST:   return lut3d_px<LUTR_INTERP_NEAREST>(L, f, r, g, b);
+    case LUTR_INTERP_TRILINEAR: return lut3d_px<LUTR_INTERP_TRILINEAR>(L, f, r, g, b);
+    case LUTR_INTERP_PYRAMID:   return lut3d_px<LUTR_INTERP_PYRAMID>(L, f, r, g, b);
+    case LUTR_INTERP_PRISM:     return lut3d_px<LUTR_INTERP_PRISM>(L, f, r, g, b);
+    default:                    return lut3d_px<LUTR_INTERP_TETRAHEDRAL>(L, f, r, g, b);
+    }
+}
+
+// ---------------------------------------------------------------- YUV contract pieces
+struct Chroma { float rv, gv, bu; };
+
+__device__ __forceinline__ float clip_floor(float v, float hi) { return med3(floorf(v), 0.0f, hi); }
+
+__device__ __forceinline__ Chroma chroma_terms(const YuvConsts &K, float cbv, float crv)
+{
+    if (K.pre != 0.0f) {
+        cbv = clip_floor(fma_(K.pc, cbv, K.pcb), K.pre_max);
+        crv = clip_floor(fma_(K.pc, crv, K.pcb), K.pre_max);
+    }
+    const float cb = cbv - K.coff, cr = crv - K.coff;
+    Chroma c;
+    c.rv = K.krv * cr;
+    c.gv = fma_(K.kgu, cb, K.kgv * cr);
+    c.bu = K.kbu * cb;
+    return c;
+}
+
+__device__ __forceinline__ Rgb yuv_to_rgb(const YuvConsts &K, float yv, const Chroma &c)
+{
+    if (K.pre != 0.0f)
+        yv = clip_floor(fma_(K.py, yv, K.pyb), K.pre_max);
+    const float yy = fma_(K.ky, yv, K.yb);
+    Rgb o;
+    o.r = clip_floor(yy + c.rv, K.max_l);
+    o.g = clip_floor(yy + c.gv, K.max_l);
+    o.b = clip_floor(yy + c.bu, K.max_l);
+    return o;
+}
+
+__device__ __forceinline__ float rgb_to_y(const YuvConsts &K, const Rgb &q)
+{
+    return clip_floor(fma_(K.cyr, q.r, fma_(K.cyg, q.g, fma_(K.cyb, q.b, K.yob))), K.max_o);
+}
+
+__device__ __forceinline__ float rgb_to_cb(const YuvConsts &K, float rs, float gs, float bs)
+{
+    return clip_floor(fma_(K.cbr, rs, fma_(K.cbg, gs, fma_(K.cbb, bs, K.cob))), K.max_o);
+}
+
+__device__ __forceinline__ float rgb_to_cr(const YuvConsts &K, float rs, float gs, float bs)
+{
+    return clip_floor(fma_(K.crr, rs, fma_(K.crg, gs, fma_(K.crb, bs, K.cob))), K.max_o);
+}
+
+// ---------------------------------------------------------------- sample access
+__device__ __forceinline__ float ld_sample(const uint8_t *row, int x, int wide)
+{
+    return wide ? (float)((const uint16_t *)row)[x] : (float)row[x];
+}
+
+__device__ __forceinline__ void st_sample(uint8_t *row, int x, int wide, float v)
+{
+    const unsigned u = (unsigned)v;
+    if (wide) ((uint16_t *)row)[x] = (uint16_t)u;
+    else row[x] = (uint8_t)u;
+}
+
+// sample i of a little-endian word vector (i is a compile-time constant after unrolling)
+template <int WIDE>
+__device__ __forceinline__ float word_sample(const uint32_t *w, int i)
+{
+    if constexpr (WIDE) return (float)((w[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+    else return (float)((w[i >> 2] >> ((i & 3) * 8)) & 0xffu);
+}
+
+template <int WIDE>
+__device__ __forceinline__ void word_put(uint32_t *w, int i, float v)
+{
+    const uint32_t u = (uint32_t)v;
+    if constexpr (WIDE) w[i >> 1] |= u << ((i & 1) * 16);
+    else w[i >> 2] |= u << ((i & 3) * 8);
+}
+
+template <int NW>
+__device__ __forceinline__ void ld_words(uint32_t *w, const uint8_t *p)
+{
+    if constexpr (NW == 4) {
+        const uint4 v = *(const uint4 *)p;
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else if constexpr (NW == 2) {
+        const uint2 v = *(const uint2 *)p;
+        w[0] = v.x; w[1] = v.y;
+    } else {
+        w[0] = *(const uint32_t *)p;
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void st_words(uint8_t *p, const uint32_t *w)
+{
+    if constexpr (NW == 4) *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]);
+    else if constexpr (NW == 2) *(uint2 *)p = make_uint2(w[0], w[1]);
+    else *(uint32_t *)p = w[0];
+}
+
+// ================================================================= generic kernels
+// Any depth 8..16, any strides/alignment, odd sizes, all five modes.  One thread per
+// pixel (RGB) or per chroma block (YUV).  This is the ragged-input path, not the fast one.
+
+__global__ __launch_bounds__(256) void k_rgb_generic(LutConsts L, PlaneSet P, FrameGeom G, int wide, int mode)
+{
+    const GFetch f(L);
+    const long long total = (long long)G.w * G.rows * G.nframes;
+    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (long long)gridDim.x * 256ll) {
+        const int x = (int)(u % G.w);
+        const long long t = u / G.w;
+        const int y = G.row0 + (int)(t % G.rows);
+        const long long fr = t / G.rows;
+        const float g = ld_sample(P.s[0] + fr * P.sfs[0] + y * P.ss[0], x, wide);
+        const float b = ld_sample(P.s[1] + fr * P.sfs[1] + y * P.ss[1], x, wide);
+        const float r = ld_sample(P.s[2] + fr * P.sfs[2] + y * P.ss[2], x, wide);
+        const Rgb o = lut3d_px_rt(mode, L, f, r, g, b);
+        st_sample(P.d[0] + fr * P.dfs[0] + y * P.ds[0], x, wide, o.g);
+        st_sample(P.d[1] + fr * P.dfs[1] + y * P.ds[1], x, wide, o.b);
+        st_sample(P.d[2] + fr * P.dfs[2] + y * P.ds[2], x, wide, o.r);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_yuv_generic(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G,
+                                                     int win, int wout, int csx, int csy, int mode)
+{
+    const GFetch f(L);
+    const int bw = 1 << csx, bh = 1 << csy;
+    const int cw = (G.w + bw - 1) >> csx;             // chroma blocks per row
+    const int cr0 = G.row0 >> csy;
+    const int crows = ((G.row0 + G.rows + bh - 1) >> csy) - cr0;
+    const long long total = (long long)cw * crows * G.nframes;
+    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (long long)gridDim.x * 256ll) {
+        const int cx = (int)(u % cw);
+        const long long t = u / cw;
+        const int cy = cr0 + (int)(t % crows);
+        const long long fr = t / crows;
+        const float cbv = ld_sample(P.s[1] + fr * P.sfs[1] + cy * P.ss[1], cx, win);
+        const float crv = ld_sample(P.s[2] + fr * P.sfs[2] + cy * P.ss[2], cx, win);
+        const Chroma c = chroma_terms(K, cbv, crv);
+        float rs = 0.f, gs = 0.f, bs = 0.f;
+        for (int dy = 0; dy < bh; dy++) {
+            const int yy = cy * bh + dy;
+            const int y = yy < G.h ? yy : G.h - 1;    // odd height: replicate the edge row into the block
+            for (int dx = 0; dx < bw; dx++) {
+                const int xx = cx * bw + dx;
+                const int x = xx < G.w ? xx : G.w - 1;
+                const float yv = ld_sample(P.s[0] + fr * P.sfs[0] + y * P.ss[0], x, win);
+                const Rgb q = yuv_to_rgb(K, yv, c);
+                const Rgb o = lut3d_px_rt(mode, L, f, q.r, q.g, q.b);
+                rs += o.r; gs += o.g; bs += o.b;
+                if (yy < G.h && xx < G.w)
+                    st_sample(P.d[0] + fr * P.dfs[0] + y * P.ds[0], x, wout, rgb_to_y(K, o));
+            }
+        }
+        st_sample(P.d[1] + fr * P.dfs[1] + cy * P.ds[1], cx, wout, rgb_to_cb(K, rs, gs, bs));
+        st_sample(P.d[2] + fr * P.dfs[2] + cy * P.ds[2], cx, wout, rgb_to_cr(K, rs, gs, bs));
+    }
+}
+
+// ================================================================= vector kernels, global gather
+// 16-byte loads/stores per plane row: 8 px (16-bit containers) or 16 px (8-bit) per thread.
+
+template <int WIDE, int INTERP>
+__global__ __launch_bounds__(256) void k_rgb_vec(LutConsts L, PlaneSet P, FrameGeom G)
+{
+    constexpr int PXT = WIDE ? 8 : 16;
+    const GFetch f(L);
+    const unsigned uw = (unsigned)G.w / PXT;
+    const unsigned total = uw * (unsigned)G.rows * (unsigned)G.nframes;
+    const unsigned u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= total) return;
+    const unsigned xu = u % uw, t = u / uw;
+    const int y = G.row0 + (int)(t % (unsigned)G.rows);
+    const long long fr = t / (unsigned)G.rows;
+    const long long xo = (long long)xu * 16;
+    uint32_t gw[4], bw[4], rw[4], go[4] = {0, 0, 0, 0}, bo[4] = {0, 0, 0, 0}, ro[4] = {0, 0, 0, 0};
+    ld_words<4>(gw, P.s[0] + fr * P.sfs[0] + y * P.ss[0] + xo);
+    ld_words<4>(bw, P.s[1] + fr * P.sfs[1] + y * P.ss[1] + xo);
+    ld_words<4>(rw, P.s[2] + fr * P.sfs[2] + y * P.ss[2] + xo);
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        const Rgb o = lut3d_px<INTERP>(L, f, word_sample<WIDE>(rw, i), word_sample<WIDE>(gw, i),
+                                       word_sample<WIDE>(bw, i));
+        word_put<WIDE>(go, i, o.g);
+        word_put<WIDE>(bo, i, o.b);
+        word_put<WIDE>(ro, i, o.r);
+    }
+    st_words<4>(P.d[0] + fr * P.dfs[0] + y * P.ds[0] + xo, go);
+    st_words<4>(P.d[1] + fr * P.dfs[1] + y * P.ds[1] + xo, bo);
+    st_words<4>(P.d[2] + fr * P.dfs[2] + y * P.ds[2] + xo, ro);
+}
+
+template <int WIDE, int CSX, int CSY, int INTERP>
+__global__ __launch_bounds__(256) void k_yuv_vec(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G)
+{
+    constexpr int PXT = WIDE ? 8 : 16;                    // luma samples per thread per row
+    constexpr int BH = 1 << CSY, BW = 1 << CSX;
+    constexpr int NC = PXT >> CSX;                        // chroma samples per thread
+    constexpr int CW = NC * (WIDE ? 2 : 1) / 4;           // chroma words per thread (2 or 4)
+    const GFetch f(L);
+    const unsigned uw = (unsigned)G.w / PXT;
+    const unsigned ub = (unsigned)G.rows >> CSY;
+    const unsigned total = uw * ub * (unsigned)G.nframes;
+    const unsigned u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= total) return;
+    const unsigned xu = u % uw, t = u / uw;
+    const int cy = (G.row0 >> CSY) + (int)(t % ub);
+    const long long fr = t / ub;
+    const long long xo = (long long)xu * 16, cxo = (long long)xu * (CW * 4);
+
+    uint32_t yw[BH][4], cbw[CW], crw[CW];
+    uint32_t yo[BH][4], cbo[CW], cro[CW];
+#pragma unroll
+    for (int dy = 0; dy < BH; dy++) {
+        ld_words<4>(yw[dy], P.s[0] + fr * P.sfs[0] + (long long)(cy * BH + dy) * P.ss[0] + xo);
+#pragma unroll
+        for (int k = 0; k < 4; k++) yo[dy][k] = 0;
+    }
+    ld_words<CW>(cbw, P.s[1] + fr * P.sfs[1] + (long long)cy * P.ss[1] + cxo);
+    ld_words<CW>(crw, P.s[2] + fr * P.sfs[2] + (long long)cy * P.ss[2] + cxo);
+#pragma unroll
+    for (int k = 0; k < CW; k++) { cbo[k] = 0; cro[k] = 0; }
+
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        const Chroma c = chroma_terms(K, word_sample<WIDE>(cbw, j), word_sample<WIDE>(crw, j));
+        float rs = 0.f, gs = 0.f, bs = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < BH; dy++) {
+#pragma unroll
+            for (int dx = 0; dx < BW; dx++) {
+                const int i = j * BW + dx;
+                const Rgb q = yuv_to_rgb(K, word_sample<WIDE>(yw[dy], i), c);
+                const Rgb o = lut3d_px<INTERP>(L, f, q.r, q.g, q.b);
+                rs += o.r; gs += o.g; bs += o.b;
+                word_put<WIDE>(yo[dy], i, rgb_to_y(K, o));
+            }
+        }
+        word_put<WIDE>(cbo, j, rgb_to_cb(K, rs, gs, bs));
+        word_put<WIDE>(cro, j, rgb_to_cr(K, rs, gs, bs));
+    }
+#pragma unroll
+    for (int dy = 0; dy < BH; dy++)
+        st_words<4>(P.d[0] + fr * P.dfs[0] + (long long)(cy * BH + dy) * P.ds[0] + xo, yo[dy]);
+    st_words<CW>(P.d[1] + fr * P.dfs[1] + (long long)cy * P.ds[1] + cxo, cbo);
+    st_words<CW>(P.d[2] + fr * P.dfs[2] + (long long)cy * P.ds[2] + cxo, cro);
+}
+
+// ================================================================= launchers
+static inline bool aligned_to(const void *p, long long a) { return ((uintptr_t)p % (uintptr_t)a) == 0; }
+
+static bool planes_aligned(const PlaneSet &P, int plane, long long a, bool batch)
+{
+    if (!aligned_to(P.s[plane], a) || !aligned_to(P.d[plane], a)) return false;
+    if (P.ss[plane] % a || P.ds[plane] % a) return false;
+    if (batch && (P.sfs[plane] % a || P.dfs[plane] % a)) return false;
+    return true;
+}
+
+static unsigned grid_for(long long units, unsigned cap = 0x7fffffffu)
+{
+    long long b = (units + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > (long long)cap) b = cap;
+    return (unsigned)b;
+}
+
+const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const PlaneSet &P,
+                       const FrameGeom &G, int depth, int mode)
+{
+    const int wide = depth > 8;
+    const int pxt = wide ? 8 : 16;
+    const long long px = (long long)G.w * G.rows * G.nframes;
+    bool vec_ok = (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
+                  G.w % pxt == 0 && px / pxt < 0x7fffffffll;
+    for (int c = 0; c < 3 && vec_ok; c++)
+        vec_ok = planes_aligned(P, c, 16, G.nframes > 1);
+    if (variant == VAR_GENERIC) vec_ok = false;
+    if (!vec_ok) {
+        if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
+        // grid-stride; enough blocks to fill 256 CUs x 8
+        hipLaunchKernelGGL(k_rgb_generic, dim3(grid_for(px, 256 * 64)), dim3(256), 0, st, L, P, G, wide, mode);
+        return "k_rgb_generic";
+    }
+    const dim3 grid(grid_for(px / pxt)), block(256);
+#define RGB_CASE(W, I) \
+    if (wide == W && mode == I) { \
+        hipLaunchKernelGGL((k_rgb_vec<W, I>), grid, block, 0, st, L, P, G); \
+        return "k_rgb_vec<" #W "," #I ">"; \
+    }
+    RGB_CASE(0, 0) RGB_CASE(0, 1) RGB_CASE(0, 2)
+    RGB_CASE(1, 0) RGB_CASE(1, 1) RGB_CASE(1, 2)
+#undef RGB_CASE
+    return nullptr;
+}
+
+const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const YuvConsts &K,
+                       const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy, int mode)
+{
+    const int win = din > 8, wout = dout > 8;
+    const int pxt = win ? 8 : 16;
+    const int bh = 1 << csy;
+    const long long cbytes = (long long)(pxt >> csx) * (win ? 2 : 1);      // chroma bytes per thread
+    bool vec_ok = (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
+                  win == wout && G.w % pxt == 0 && G.row0 % bh == 0 && G.rows % bh == 0 &&
+                  !(csx == 0 && csy == 1) &&
+                  (long long)(G.w / pxt) * (G.rows >> csy) * G.nframes < 0x7fffffffll;
+    if (vec_ok) vec_ok = planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, cbytes, G.nframes > 1) &&
+                         planes_aligned(P, 2, cbytes, G.nframes > 1);
+    if (variant == VAR_GENERIC) vec_ok = false;
+    if (!vec_ok) {
+        if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
+        const long long blocks = (long long)((G.w + (1 << csx) - 1) >> csx) * ((G.rows + bh - 1) >> csy) * G.nframes;
+        hipLaunchKernelGGL(k_yuv_generic, dim3(grid_for(blocks, 256 * 64)), dim3(256), 0, st, L, K, P, G, win, wout,
+                           csx, csy, mode);
+        return "k_yuv_generic";
+    }
+    const long long units = (long long)(G.w / pxt) * (G.rows >> csy) * G.nframes;
+    const dim3 grid(grid_for(units)), block(256);
+#define YUV_CASE(W, X, Y, I) \
+    if (win == W && csx == X && csy == Y && mode == I) { \
+        hipLaunchKernelGGL((k_yuv_vec<W, X, Y, I>), grid, block, 0, st, L, K, P, G); \
+        return "k_yuv_vec<" #W "," #X "," #Y "," #I ">"; \
+    }
+#define YUV_FMT(W, X, Y) YUV_CASE(W, X, Y, 0) YUV_CASE(W, X, Y, 1) YUV_CASE(W, X, Y, 2)
+    YUV_FMT(0, 1, 1) YUV_FMT(0, 1, 0) YUV_FMT(0, 0, 0)
+    YUV_FMT(1, 1, 1) YUV_FMT(1, 1, 0) YUV_FMT(1, 0, 0)
+#undef YUV_FMT
+#undef YUV_CASE
+    return nullptr;
+}
+
+}  // namespace lutr

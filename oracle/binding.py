@@ -1,0 +1,162 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liblut3d_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package (lut_renderer_amd).  See the header of
+oracle/lut3d_oracle.h for what the oracle restates and why parity is "unpinned".
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "_build" / "liblut3d_oracle.so"
+
+INTERP = {"nearest": 0, "trilinear": 1, "tetrahedral": 2, "pyramid": 3, "prism": 4}
+MATRIX = {"bt709": 0, "smpte170m": 1, "bt470bg": 1, "bt601": 1, "bt2020nc": 2, "bt2020c": 2}
+RANGE = {"tv": 0, "pc": 1}
+
+
+class OrcLut(C.Structure):
+    _fields_ = [("n", C.c_int), ("scale", C.c_float * 3), ("rgb", C.POINTER(C.c_float))]
+
+
+class YuvConsts(C.Structure):
+    _fields_ = (
+        [(k, C.c_float) for k in ("ky", "yb", "coff", "krv", "kgu", "kgv", "kbu", "max_l",
+                                  "cyr", "cyg", "cyb", "yob", "cbr", "cbg", "cbb",
+                                  "crr", "crg", "crb", "cob", "max_o")]
+        + [("pre", C.c_int)]
+        + [(k, C.c_float) for k in ("py", "pyb", "pc", "pcb", "pre_max")]
+    )
+
+    def as_block(self) -> np.ndarray:
+        """Same 32-float layout liblutr's lutr_yuv_constants() returns."""
+        vals = [getattr(self, k) for k, _ in self._fields_[:20]]
+        vals.append(float(self.pre))
+        vals += [self.py, self.pyb, self.pc, self.pcb, self.pre_max]
+        vals += [0.0] * (32 - len(vals))
+        return np.array(vals, dtype=np.float32)
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code: int):
+        super().__init__(f"oracle error {code}")
+        self.code = code
+
+
+_lib = None
+
+
+def build() -> Path:
+    subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        lib = C.CDLL(str(LIB_PATH))
+        P3 = C.c_void_p * 3
+        S3 = C.c_ssize_t * 3
+        lib.orc_cube_parse.argtypes = [C.c_char_p, C.POINTER(OrcLut)]
+        lib.orc_lut_free.argtypes = [C.POINTER(OrcLut)]
+        lib.orc_lut_free.restype = None
+        lib.orc_apply_planar_rgb.argtypes = [C.POINTER(OrcLut), C.c_int, C.c_int, C.c_int, C.c_int,
+                                             P3, S3, P3, S3, C.c_int]
+        lib.orc_apply_pixel.argtypes = [C.POINTER(OrcLut), C.c_int, C.c_int, C.c_int * 3, C.c_int * 3]
+        lib.orc_yuv_constants.argtypes = [C.c_int] * 9 + [C.POINTER(YuvConsts)]
+        lib.orc_apply_yuv.argtypes = [C.POINTER(OrcLut), C.c_int, C.POINTER(YuvConsts)] + [C.c_int] * 7 + \
+                                     [P3, S3, P3, S3, C.c_int]
+        _lib = lib
+    return _lib
+
+
+def parse_cube(path):
+    """-> (n, scale float32[3], table float32[n,n,n,3]); raises OracleError(code)."""
+    lib = load()
+    lut = OrcLut()
+    rc = lib.orc_cube_parse(str(path).encode(), C.byref(lut))
+    if rc:
+        raise OracleError(rc)
+    try:
+        n = lut.n
+        table = np.ctypeslib.as_array(lut.rgb, shape=(n * n * n * 3,)).astype(np.float32, copy=True)
+        scale = np.array(list(lut.scale), dtype=np.float32)
+    finally:
+        lib.orc_lut_free(C.byref(lut))
+    return n, scale, table.reshape(n, n, n, 3)
+
+
+def _lut_struct(table: np.ndarray, scale) -> tuple:
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    lut = OrcLut()
+    lut.n = table.shape[0]
+    for i in range(3):
+        lut.scale[i] = float(scale[i])
+    lut.rgb = table.ctypes.data_as(C.POINTER(C.c_float))
+    return lut, table      # keep `table` alive alongside the struct
+
+
+def _plane_args(planes):
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+    strides = (C.c_ssize_t * 3)(*[p.strides[0] for p in planes])
+    return ptrs, strides
+
+
+def apply_pixel(table, scale, depth: int, interp: str, rgb) -> tuple:
+    lut, _keep = _lut_struct(table, scale)
+    inp = (C.c_int * 3)(*[int(v) for v in rgb])
+    out = (C.c_int * 3)()
+    rc = load().orc_apply_pixel(C.byref(lut), depth, INTERP[interp], inp, out)
+    if rc:
+        raise OracleError(rc)
+    return tuple(out)
+
+
+def apply_rgb(table, scale, depth: int, interp: str, planes, nthreads: int = 1):
+    """planes: (G, B, R) arrays [H,W] uint8 (depth 8) or uint16; returns new (G, B, R)."""
+    lut, _keep = _lut_struct(table, scale)
+    src = [np.ascontiguousarray(p) for p in planes]
+    dst = [np.empty_like(p) for p in src]
+    h, w = src[0].shape
+    sp, ss = _plane_args(src)
+    dp, ds = _plane_args(dst)
+    rc = load().orc_apply_planar_rgb(C.byref(lut), depth, INTERP[interp], w, h, sp, ss, dp, ds, nthreads)
+    if rc:
+        raise OracleError(rc)
+    return dst
+
+
+def yuv_constants(matrix_in="bt709", range_in="tv", matrix_out=None, range_out="tv",
+                  din=8, dl=None, dout=None, chroma_n=4, prologue=False) -> YuvConsts:
+    k = YuvConsts()
+    dl = din if dl is None else dl
+    dout = dl if dout is None else dout
+    rc = load().orc_yuv_constants(MATRIX[matrix_in], RANGE[range_in], MATRIX[matrix_out or matrix_in],
+                                  RANGE[range_out], din, dl, dout, chroma_n, int(bool(prologue)), C.byref(k))
+    if rc:
+        raise OracleError(rc)
+    return k
+
+
+def apply_yuv(table, scale, interp: str, consts: YuvConsts, din: int, dl: int, dout: int,
+              csx: int, csy: int, planes, nthreads: int = 1):
+    """planes: (Y, Cb, Cr) arrays; returns new (Y, Cb, Cr) with the output container dtype."""
+    lut, _keep = _lut_struct(table, scale)
+    src = [np.ascontiguousarray(p) for p in planes]
+    odt = np.uint8 if dout <= 8 else np.uint16
+    dst = [np.zeros(p.shape, dtype=odt) for p in src]
+    h, w = src[0].shape
+    sp, ss = _plane_args(src)
+    dp, ds = _plane_args(dst)
+    rc = load().orc_apply_yuv(C.byref(lut), INTERP[interp], C.byref(consts), din, dl, dout, csx, csy, w, h,
+                              sp, ss, dp, ds, nthreads)
+    if rc:
+        raise OracleError(rc)
+    return dst

@@ -1,0 +1,685 @@
+/*
+ * oracle/lut3d_oracle.c -- TEST INFRASTRUCTURE ONLY (see lut3d_oracle.h header note).
+ *
+ * Plain scalar C restatement, compiled with -ffp-contract=off so every
+ * product and sum below rounds exactly where the C source says it does.
+ *
+ * What it follows:
+ *   - .cube parsing and the lut3d per-pixel pipeline: FFmpeg libavfilter/vf_lut3d.c
+ *     as distilled in SURVEY.md Appendix A.1-A.5 (the filter the reference emits
+ *     at /root/reference/src/lut_renderer/ffmpeg.py:246).  FFmpeg is a third-party,
+ *     un-vendored, un-pinned dependency of the reference (readme.md:29), so the
+ *     published algorithm is restated here.  PARITY UNPINNED vs a live ffmpeg.
+ *   - YUV<->RGB / range handling: the filters the reference puts around lut3d
+ *     (ffmpeg.py:212-236 scale=..., :224/:233 format=<8-bit intermediate>,
+ *     :304-310 format=<pix_fmt>).  swscale's fixed-point arithmetic is unpinned
+ *     and version dependent, so the engine defines its own
+ *     real-arithmetic contract (DESIGN.md "YUV contract"); this file is that
+ *     contract's executable definition.
+ */
+#include "lut3d_oracle.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAX_LINE_SIZE 512   /* vf_lut3d.c MAX_LINE_SIZE */
+#define MAX_LEVEL     256   /* vf_lut3d.c MAX_LEVEL */
+
+typedef struct { float r, g, b; } rgbvec;
+
+/* ------------------------------------------------------------------ */
+/* .cube parser: SURVEY.md A.2 (vf_lut3d.c parse_cube)                 */
+/* ------------------------------------------------------------------ */
+
+static int skip_line(const char *p)
+{
+    while (*p && isspace((unsigned char)*p))
+        p++;
+    return !*p || *p == '#';
+}
+
+static int has_ext_cube(const char *path)
+{
+    const char *dot = strrchr(path, '.');
+    if (!dot)
+        return 0;
+    dot++;
+    return (tolower((unsigned char)dot[0]) == 'c' && tolower((unsigned char)dot[1]) == 'u' &&
+            tolower((unsigned char)dot[2]) == 'b' && tolower((unsigned char)dot[3]) == 'e' && dot[4] == 0);
+}
+
+int orc_cube_parse(const char *path, orc_lut *out)
+{
+    char line[MAX_LINE_SIZE];
+    float min[3] = {0.0f, 0.0f, 0.0f};
+    float max[3] = {1.0f, 1.0f, 1.0f};
+    FILE *f;
+    int found = 0;
+
+    if (!path || !out)
+        return ORC_EINVAL;
+    memset(out, 0, sizeof(*out));
+    /* lut3d picks the parser by extension; no/unknown extension is an error */
+    if (!has_ext_cube(path))
+        return ORC_EINVAL;
+    f = fopen(path, "r");
+    if (!f)
+        return ORC_ENOENT;
+
+    /* every line before LUT_3D_SIZE is ignored, including DOMAIN_xxx and TITLE (quirk, A.2) */
+    while (fgets(line, sizeof(line), f)) {
+        if (!strncmp(line, "LUT_3D_SIZE", 11)) {
+            const int size = (int)strtol(line + 12, NULL, 0);
+            int i, j, k;
+            if (size < 2 || size > MAX_LEVEL) {
+                fclose(f);
+                return ORC_EINVAL;
+            }
+            out->n = size;
+            out->rgb = (float *)malloc((size_t)size * size * size * 3 * sizeof(float));
+            if (!out->rgb) {
+                fclose(f);
+                return ORC_ENOMEM;
+            }
+            /* file order: R fastest, then G, then B; stored blue-fastest lut[i][j][k] */
+            for (k = 0; k < size; k++) {
+                for (j = 0; j < size; j++) {
+                    for (i = 0; i < size; i++) {
+                        float *vec = &out->rgb[(((size_t)i * size + j) * size + k) * 3];
+                        for (;;) {
+                            if (!fgets(line, sizeof(line), f)) {   /* "Unexpected EOF" */
+                                fclose(f);
+                                orc_lut_free(out);
+                                return ORC_EILSEQ;
+                            }
+                            if (!strncmp(line, "DOMAIN_", 7)) {
+                                float *vals = NULL;
+                                if (!strncmp(line + 7, "MIN ", 4))
+                                    vals = min;
+                                else if (!strncmp(line + 7, "MAX ", 4))
+                                    vals = max;
+                                if (!vals) {
+                                    fclose(f);
+                                    orc_lut_free(out);
+                                    return ORC_EILSEQ;
+                                }
+                                sscanf(line + 11, "%f %f %f", vals, vals + 1, vals + 2);
+                                continue;
+                            }
+                            if (!strncmp(line, "TITLE", 5))
+                                continue;
+                            if (skip_line(line))
+                                continue;
+                            break;
+                        }
+                        if (sscanf(line, "%f %f %f", &vec[0], &vec[1], &vec[2]) != 3) {
+                            fclose(f);
+                            orc_lut_free(out);
+                            return ORC_EILSEQ;
+                        }
+                    }
+                }
+            }
+            found = 1;
+            break;
+        }
+    }
+    fclose(f);
+    if (!found) {          /* "3D LUT is empty" */
+        orc_lut_free(out);
+        return ORC_EILSEQ;
+    }
+    /* scale = clip(1/(max-min), 0, 1); min is never subtracted from the input (A.2) */
+    for (int c = 0; c < 3; c++) {
+        float s = (float)(1.0 / ((double)max[c] - (double)min[c]));
+        if (s < 0.f) s = 0.f;     /* av_clipf(x, 0, 1) = min(max(x,0),1) */
+        if (s > 1.f) s = 1.f;
+        if (s != s) s = 0.f;      /* NaN from 0/0 domain: treat as degenerate */
+        out->scale[c] = s;
+    }
+    return 0;
+}
+
+void orc_lut_free(orc_lut *lut)
+{
+    if (lut) {
+        free(lut->rgb);
+        lut->rgb = NULL;
+        lut->n = 0;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* interpolation: SURVEY.md A.4 / A.5 (vf_lut3d.c interp_*)            */
+/* ------------------------------------------------------------------ */
+
+static inline rgbvec node(const orc_lut *l, int r, int g, int b)
+{
+    const float *p = &l->rgb[(((size_t)r * l->n + g) * l->n + b) * 3];
+    rgbvec v = {p[0], p[1], p[2]};
+    return v;
+}
+
+#define PREV(x) ((int)(x))
+#define NEXT(x, n) (((int)(x) + 1) < (n) - 1 ? ((int)(x) + 1) : (n) - 1)
+#define NEAR(x) ((int)((x) + .5f))
+
+static inline float lerpf(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
+
+static inline rgbvec lerp(rgbvec a, rgbvec b, float f)
+{
+    rgbvec v = {lerpf(a.r, b.r, f), lerpf(a.g, b.g, f), lerpf(a.b, b.b, f)};
+    return v;
+}
+
+static rgbvec interp_nearest(const orc_lut *l, rgbvec s)
+{
+    return node(l, NEAR(s.r), NEAR(s.g), NEAR(s.b));
+}
+
+static rgbvec interp_trilinear(const orc_lut *l, rgbvec s)
+{
+    const int n = l->n;
+    const int p[3] = {PREV(s.r), PREV(s.g), PREV(s.b)};
+    const int x[3] = {NEXT(s.r, n), NEXT(s.g, n), NEXT(s.b, n)};
+    const rgbvec d = {s.r - p[0], s.g - p[1], s.b - p[2]};
+    const rgbvec c000 = node(l, p[0], p[1], p[2]);
+    const rgbvec c001 = node(l, p[0], p[1], x[2]);
+    const rgbvec c010 = node(l, p[0], x[1], p[2]);
+    const rgbvec c011 = node(l, p[0], x[1], x[2]);
+    const rgbvec c100 = node(l, x[0], p[1], p[2]);
+    const rgbvec c101 = node(l, x[0], p[1], x[2]);
+    const rgbvec c110 = node(l, x[0], x[1], p[2]);
+    const rgbvec c111 = node(l, x[0], x[1], x[2]);
+    const rgbvec c00 = lerp(c000, c100, d.r);
+    const rgbvec c10 = lerp(c010, c110, d.r);
+    const rgbvec c01 = lerp(c001, c101, d.r);
+    const rgbvec c11 = lerp(c011, c111, d.r);
+    const rgbvec c0 = lerp(c00, c10, d.g);
+    const rgbvec c1 = lerp(c01, c11, d.g);
+    return lerp(c0, c1, d.b);
+}
+
+#define TETRA(w0, v0, w1, v1, w2, v2, w3, v3) \
+    do { \
+        c.r = (w0) * v0.r + (w1) * v1.r + (w2) * v2.r + (w3) * v3.r; \
+        c.g = (w0) * v0.g + (w1) * v1.g + (w2) * v2.g + (w3) * v3.g; \
+        c.b = (w0) * v0.b + (w1) * v1.b + (w2) * v2.b + (w3) * v3.b; \
+    } while (0)
+
+static rgbvec interp_tetrahedral(const orc_lut *l, rgbvec s)
+{
+    const int n = l->n;
+    const int p[3] = {PREV(s.r), PREV(s.g), PREV(s.b)};
+    const int x[3] = {NEXT(s.r, n), NEXT(s.g, n), NEXT(s.b, n)};
+    const rgbvec d = {s.r - p[0], s.g - p[1], s.b - p[2]};
+    const rgbvec c000 = node(l, p[0], p[1], p[2]);
+    const rgbvec c111 = node(l, x[0], x[1], x[2]);
+    rgbvec c;
+    if (d.r > d.g) {
+        if (d.g > d.b) {
+            const rgbvec c100 = node(l, x[0], p[1], p[2]);
+            const rgbvec c110 = node(l, x[0], x[1], p[2]);
+            TETRA(1 - d.r, c000, d.r - d.g, c100, d.g - d.b, c110, d.b, c111);
+        } else if (d.r > d.b) {
+            const rgbvec c100 = node(l, x[0], p[1], p[2]);
+            const rgbvec c101 = node(l, x[0], p[1], x[2]);
+            TETRA(1 - d.r, c000, d.r - d.b, c100, d.b - d.g, c101, d.g, c111);
+        } else {
+            const rgbvec c001 = node(l, p[0], p[1], x[2]);
+            const rgbvec c101 = node(l, x[0], p[1], x[2]);
+            TETRA(1 - d.b, c000, d.b - d.r, c001, d.r - d.g, c101, d.g, c111);
+        }
+    } else {
+        if (d.b > d.g) {
+            const rgbvec c001 = node(l, p[0], p[1], x[2]);
+            const rgbvec c011 = node(l, p[0], x[1], x[2]);
+            TETRA(1 - d.b, c000, d.b - d.g, c001, d.g - d.r, c011, d.r, c111);
+        } else if (d.b > d.r) {
+            const rgbvec c010 = node(l, p[0], x[1], p[2]);
+            const rgbvec c011 = node(l, p[0], x[1], x[2]);
+            TETRA(1 - d.g, c000, d.g - d.b, c010, d.b - d.r, c011, d.r, c111);
+        } else {
+            const rgbvec c010 = node(l, p[0], x[1], p[2]);
+            const rgbvec c110 = node(l, x[0], x[1], p[2]);
+            TETRA(1 - d.g, c000, d.g - d.r, c010, d.r - d.b, c110, d.b, c111);
+        }
+    }
+    return c;
+}
+
+/* pyramid / prism: newer FFmpeg modes the reference whitelists (ffmpeg.py:243) but
+ * the GUI never offers (main_window.py:649-651).  Restated from recall; SURVEY 8f rank 2. */
+static rgbvec interp_pyramid(const orc_lut *l, rgbvec s)
+{
+    const int n = l->n;
+    const int p[3] = {PREV(s.r), PREV(s.g), PREV(s.b)};
+    const int x[3] = {NEXT(s.r, n), NEXT(s.g, n), NEXT(s.b, n)};
+    const rgbvec d = {s.r - p[0], s.g - p[1], s.b - p[2]};
+    const rgbvec c000 = node(l, p[0], p[1], p[2]);
+    const rgbvec c111 = node(l, x[0], x[1], x[2]);
+    rgbvec c;
+#define PYR(ch) \
+    if (d.g > d.r && d.b > d.r) { \
+        c.ch = c000.ch + (c111.ch - c011.ch) * d.r + (c010.ch - c000.ch) * d.g + (c001.ch - c000.ch) * d.b + \
+               (c011.ch - c001.ch - c010.ch + c000.ch) * d.g * d.b; \
+    } else if (d.r > d.g && d.b > d.g) { \
+        c.ch = c000.ch + (c100.ch - c000.ch) * d.r + (c111.ch - c101.ch) * d.g + (c001.ch - c000.ch) * d.b + \
+               (c101.ch - c001.ch - c100.ch + c000.ch) * d.r * d.b; \
+    } else { \
+        c.ch = c000.ch + (c100.ch - c000.ch) * d.r + (c010.ch - c000.ch) * d.g + (c111.ch - c110.ch) * d.b + \
+               (c110.ch - c100.ch - c010.ch + c000.ch) * d.r * d.g; \
+    }
+    const rgbvec c001 = node(l, p[0], p[1], x[2]);
+    const rgbvec c010 = node(l, p[0], x[1], p[2]);
+    const rgbvec c011 = node(l, p[0], x[1], x[2]);
+    const rgbvec c100 = node(l, x[0], p[1], p[2]);
+    const rgbvec c101 = node(l, x[0], p[1], x[2]);
+    const rgbvec c110 = node(l, x[0], x[1], p[2]);
+    PYR(r) PYR(g) PYR(b)
+#undef PYR
+    return c;
+}
+
+static rgbvec interp_prism(const orc_lut *l, rgbvec s)
+{
+    const int n = l->n;
+    const int p[3] = {PREV(s.r), PREV(s.g), PREV(s.b)};
+    const int x[3] = {NEXT(s.r, n), NEXT(s.g, n), NEXT(s.b, n)};
+    const rgbvec d = {s.r - p[0], s.g - p[1], s.b - p[2]};
+    const rgbvec c000 = node(l, p[0], p[1], p[2]);
+    const rgbvec c001 = node(l, p[0], p[1], x[2]);
+    const rgbvec c010 = node(l, p[0], x[1], p[2]);
+    const rgbvec c011 = node(l, p[0], x[1], x[2]);
+    const rgbvec c100 = node(l, x[0], p[1], p[2]);
+    const rgbvec c101 = node(l, x[0], p[1], x[2]);
+    const rgbvec c110 = node(l, x[0], x[1], p[2]);
+    const rgbvec c111 = node(l, x[0], x[1], x[2]);
+    rgbvec c;
+#define PRI(ch) \
+    if (d.b > d.r) { \
+        c.ch = c000.ch + (c001.ch - c000.ch) * d.b + (c101.ch - c001.ch) * d.r + (c010.ch - c000.ch) * d.g + \
+               (c000.ch - c010.ch - c001.ch + c011.ch) * d.b * d.g + \
+               (c001.ch - c011.ch - c101.ch + c111.ch) * d.r * d.g; \
+    } else { \
+        c.ch = c000.ch + (c101.ch - c100.ch) * d.b + (c100.ch - c000.ch) * d.r + (c010.ch - c000.ch) * d.g + \
+               (c100.ch - c110.ch - c101.ch + c111.ch) * d.b * d.g + \
+               (c000.ch - c010.ch - c100.ch + c110.ch) * d.r * d.g; \
+    }
+    PRI(r) PRI(g) PRI(b)
+#undef PRI
+    return c;
+}
+
+static inline rgbvec interp(const orc_lut *l, int mode, rgbvec s)
+{
+    switch (mode) {
+    case ORC_NEAREST:     return interp_nearest(l, s);
+    case ORC_TRILINEAR:   return interp_trilinear(l, s);
+    case ORC_PYRAMID:     return interp_pyramid(l, s);
+    case ORC_PRISM:       return interp_prism(l, s);
+    default:              return interp_tetrahedral(l, s);
+    }
+}
+
+static inline float clipf(float a, float lo, float hi)
+{
+    /* av_clipf: FFMIN(FFMAX(a, amin), amax) */
+    const float t = a > lo ? a : lo;
+    return t > hi ? hi : t;
+}
+
+/* C float->int conversion truncates toward zero; out-of-int-range is UB in C, the
+ * oracle (like the GPU's v_cvt_i32_f32) saturates.  Then av_clip_uintp2. */
+static inline int quant(float v, float maxf, int maxi)
+{
+    float t = v * maxf;
+    int i;
+    if (!(t > -2147483648.0f)) i = INT32_MIN;      /* also NaN -> lowest */
+    else if (t >= 2147483648.0f) i = INT32_MAX;
+    else i = (int)t;
+    if (i < 0) return 0;
+    if (i > maxi) return maxi;
+    return i;
+}
+
+/* one pixel of the A.3 pipeline: integer codes in, integer codes out */
+static inline void lut_pixel(const orc_lut *l, int mode, float scale_f, const float scale_c[3],
+                             float lut_max, float maxf, int maxi,
+                             int r, int g, int b, int *ro, int *go, int *bo)
+{
+    const rgbvec rgb = {(float)r * scale_f, (float)g * scale_f, (float)b * scale_f};
+    const rgbvec s = {clipf(rgb.r * scale_c[0], 0, lut_max),
+                      clipf(rgb.g * scale_c[1], 0, lut_max),
+                      clipf(rgb.b * scale_c[2], 0, lut_max)};
+    const rgbvec v = interp(l, mode, s);
+    *ro = quant(v.r, maxf, maxi);
+    *go = quant(v.g, maxf, maxi);
+    *bo = quant(v.b, maxf, maxi);
+}
+
+typedef struct lut_consts {
+    float scale_f, scale_c[3], lut_max, maxf;
+    int maxi;
+} lut_consts;
+
+static void make_lut_consts(const orc_lut *l, int depth, lut_consts *k)
+{
+    k->maxi = (1 << depth) - 1;
+    k->maxf = (float)k->maxi;
+    k->scale_f = 1.0f / (float)k->maxi;
+    k->lut_max = (float)(l->n - 1);
+    for (int c = 0; c < 3; c++)
+        k->scale_c[c] = l->scale[c] * k->lut_max;
+}
+
+int orc_apply_pixel(const orc_lut *lut, int depth, int mode, const int in_rgb[3], int out_rgb[3])
+{
+    lut_consts k;
+    if (!lut || !lut->rgb || depth < 8 || depth > 16)
+        return ORC_EINVAL;
+    make_lut_consts(lut, depth, &k);
+    lut_pixel(lut, mode, k.scale_f, k.scale_c, k.lut_max, k.maxf, k.maxi,
+              in_rgb[0], in_rgb[1], in_rgb[2], &out_rgb[0], &out_rgb[1], &out_rgb[2]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* row-slice threading, FFmpeg style: rows [h*j/n, h*(j+1)/n)  (3.4)   */
+/* ------------------------------------------------------------------ */
+
+typedef void (*slice_fn)(void *arg, int y0, int y1);
+typedef struct { slice_fn fn; void *arg; int y0, y1; } slice_job;
+
+static void *slice_tramp(void *p)
+{
+    slice_job *j = (slice_job *)p;
+    j->fn(j->arg, j->y0, j->y1);
+    return NULL;
+}
+
+static void run_slices(slice_fn fn, void *arg, int h, int align, int nthreads)
+{
+    /* units of `align` rows so chroma blocks never straddle two slices */
+    const int units = (h + align - 1) / align;
+    int n = nthreads < 1 ? 1 : nthreads;
+    if (n > units) n = units;
+    if (n <= 1) {
+        fn(arg, 0, h);
+        return;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n);
+    slice_job *jobs = (slice_job *)malloc(sizeof(slice_job) * n);
+    for (int j = 0; j < n; j++) {
+        int a = (int)((long long)units * j / n) * align;
+        int b = (int)((long long)units * (j + 1) / n) * align;
+        if (b > h) b = h;
+        jobs[j].fn = fn; jobs[j].arg = arg; jobs[j].y0 = a; jobs[j].y1 = b;
+        pthread_create(&th[j], NULL, slice_tramp, &jobs[j]);
+    }
+    for (int j = 0; j < n; j++)
+        pthread_join(th[j], NULL);
+    free(th);
+    free(jobs);
+}
+
+/* ------------------------------------------------------------------ */
+/* planar RGB (gbrp order G,B,R): SURVEY.md A.3                        */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    const orc_lut *lut; int depth, mode, w;
+    const uint8_t *src[3]; ptrdiff_t ss[3];
+    uint8_t *dst[3]; ptrdiff_t ds[3];
+    lut_consts k;
+} rgb_job;
+
+static inline int ld(const uint8_t *row, int x, int wide)
+{
+    return wide ? ((const uint16_t *)row)[x] : row[x];
+}
+
+static inline void st(uint8_t *row, int x, int wide, int v)
+{
+    if (wide) ((uint16_t *)row)[x] = (uint16_t)v;
+    else row[x] = (uint8_t)v;
+}
+
+static void rgb_slice(void *arg, int y0, int y1)
+{
+    rgb_job *j = (rgb_job *)arg;
+    const int wide = j->depth > 8;
+    for (int y = y0; y < y1; y++) {
+        const uint8_t *sg = j->src[0] + y * j->ss[0];
+        const uint8_t *sb = j->src[1] + y * j->ss[1];
+        const uint8_t *sr = j->src[2] + y * j->ss[2];
+        uint8_t *dg = j->dst[0] + y * j->ds[0];
+        uint8_t *db = j->dst[1] + y * j->ds[1];
+        uint8_t *dr = j->dst[2] + y * j->ds[2];
+        for (int x = 0; x < j->w; x++) {
+            int ro, go, bo;
+            lut_pixel(j->lut, j->mode, j->k.scale_f, j->k.scale_c, j->k.lut_max, j->k.maxf, j->k.maxi,
+                      ld(sr, x, wide), ld(sg, x, wide), ld(sb, x, wide), &ro, &go, &bo);
+            st(dr, x, wide, ro);
+            st(dg, x, wide, go);
+            st(db, x, wide, bo);
+        }
+    }
+}
+
+int orc_apply_planar_rgb(const orc_lut *lut, int depth, int mode, int w, int h,
+                         const void *const src[3], const ptrdiff_t sstride[3],
+                         void *const dst[3], const ptrdiff_t dstride[3], int nthreads)
+{
+    rgb_job j;
+    if (!lut || !lut->rgb || depth < 8 || depth > 16 || w < 0 || h < 0 ||
+        mode < ORC_NEAREST || mode > ORC_PRISM)
+        return ORC_EINVAL;
+    if (w == 0 || h == 0)
+        return 0;
+    j.lut = lut; j.depth = depth; j.mode = mode; j.w = w;
+    for (int c = 0; c < 3; c++) {
+        j.src[c] = (const uint8_t *)src[c]; j.ss[c] = sstride[c];
+        j.dst[c] = (uint8_t *)dst[c]; j.ds[c] = dstride[c];
+    }
+    make_lut_consts(lut, depth, &j.k);
+    run_slices(rgb_slice, &j, h, 1, nthreads);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* YUV contract: constants                                 */
+/* ------------------------------------------------------------------ */
+
+static int matrix_coeffs(int m, double *kr, double *kb)
+{
+    switch (m) {
+    case ORC_MAT_BT709:  *kr = 0.2126; *kb = 0.0722; return 0;
+    case ORC_MAT_BT601:  *kr = 0.299;  *kb = 0.114;  return 0;   /* smpte170m == bt470bg */
+    case ORC_MAT_BT2020: *kr = 0.2627; *kb = 0.0593; return 0;   /* bt2020c uses nc coefficients */
+    }
+    return ORC_EINVAL;
+}
+
+int orc_yuv_constants(int matrix_in, int range_in, int matrix_out, int range_out,
+                      int din, int dl, int dout, int chroma_n, int prologue_pc_to_tv,
+                      orc_yuv_consts *o)
+{
+    double kr, kb, kg;
+    if (!o || din < 8 || din > 16 || dl < 8 || dl > 16 || dout < 8 || dout > 16 ||
+        (chroma_n != 1 && chroma_n != 2 && chroma_n != 4))
+        return ORC_EINVAL;
+    if (!prologue_pc_to_tv && din != dl)
+        return ORC_EINVAL;      /* only the prologue changes depth ahead of the LUT */
+    memset(o, 0, sizeof(*o));
+
+    /* optional prologue: scale=in_range=pc:out_range=<r>,format=<dl-bit> (ffmpeg.py:224-233).
+     * Input is full range at depth din; result is range_in's meaning at depth dl:
+     * after it the LUT-side conversion sees (range_in, dl). */
+    if (prologue_pc_to_tv) {
+        const double mi = (double)((1 << din) - 1);
+        const double sl = (double)(1 << (dl - 8));
+        const double ml = (double)((1 << dl) - 1);
+        const double half_in = (double)(1 << (din - 1));
+        double py, pyo, pc, pco;
+        if (range_in == ORC_RANGE_TV) {       /* pc -> tv */
+            py = 219.0 * sl / mi;  pyo = 16.0 * sl;
+            pc = 224.0 * sl / mi;  pco = 128.0 * sl - half_in * pc;
+        } else {                              /* pc -> pc, depth change only */
+            py = ml / mi;          pyo = 0.0;
+            pc = ml / mi;          pco = 128.0 * sl - half_in * pc;
+        }
+        o->pre = 1;
+        o->py = (float)py;  o->pyb = (float)(pyo + 0.5);
+        o->pc = (float)pc;  o->pcb = (float)(pco + 0.5);
+        o->pre_max = (float)ml;
+    }
+
+    /* input side, at depth dl */
+    if (matrix_coeffs(matrix_in, &kr, &kb))
+        return ORC_EINVAL;
+    kg = 1.0 - kr - kb;
+    {
+        const double s = (double)(1 << (dl - 8));
+        const double m = (double)((1 << dl) - 1);
+        double ky, yoff, kc;
+        if (range_in == ORC_RANGE_TV) { ky = m / (219.0 * s); yoff = 16.0 * s; kc = m / (224.0 * s); }
+        else if (range_in == ORC_RANGE_PC) { ky = 1.0; yoff = 0.0; kc = 1.0; }
+        else return ORC_EINVAL;
+        o->ky = (float)ky;
+        o->yb = (float)(-ky * yoff + 0.5);
+        o->coff = (float)(128.0 * s);
+        o->krv = (float)(2.0 * (1.0 - kr) * kc);
+        o->kbu = (float)(2.0 * (1.0 - kb) * kc);
+        o->kgu = (float)(-2.0 * kb * (1.0 - kb) / kg * kc);
+        o->kgv = (float)(-2.0 * kr * (1.0 - kr) / kg * kc);
+        o->max_l = (float)m;
+    }
+    /* output side: RGB codes at depth dl (full range) -> YUV codes at depth dout */
+    if (matrix_coeffs(matrix_out, &kr, &kb))
+        return ORC_EINVAL;
+    kg = 1.0 - kr - kb;
+    {
+        const double so = (double)(1 << (dout - 8));
+        const double mo = (double)((1 << dout) - 1);
+        const double ml = (double)((1 << dl) - 1);
+        const double n = (double)chroma_n;
+        double ys, yoff, cs;
+        if (range_out == ORC_RANGE_TV) { ys = 219.0 * so; yoff = 16.0 * so; cs = 224.0 * so; }
+        else if (range_out == ORC_RANGE_PC) { ys = mo; yoff = 0.0; cs = mo; }
+        else return ORC_EINVAL;
+        o->cyr = (float)(ys * kr / ml);
+        o->cyg = (float)(ys * kg / ml);
+        o->cyb = (float)(ys * kb / ml);
+        o->yob = (float)(yoff + 0.5);
+        o->cbr = (float)(cs * (-kr / (2.0 * (1.0 - kb))) / ml / n);
+        o->cbg = (float)(cs * (-kg / (2.0 * (1.0 - kb))) / ml / n);
+        o->cbb = (float)(cs * 0.5 / ml / n);
+        o->crr = (float)(cs * 0.5 / ml / n);
+        o->crg = (float)(cs * (-kg / (2.0 * (1.0 - kr))) / ml / n);
+        o->crb = (float)(cs * (-kb / (2.0 * (1.0 - kr))) / ml / n);
+        o->cob = (float)(128.0 * so + 0.5);
+        o->max_o = (float)mo;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* YUV contract: pixels                                                */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    const orc_lut *lut; int mode; const orc_yuv_consts *k;
+    int din, dl, dout, csx, csy, w, h;
+    const uint8_t *src[3]; ptrdiff_t ss[3];
+    uint8_t *dst[3]; ptrdiff_t ds[3];
+    lut_consts lk;
+} yuv_job;
+
+static inline float clip_floor(float v, float hi)
+{
+    return clipf(floorf(v), 0.0f, hi);
+}
+
+static void yuv_slice(void *arg, int y0, int y1)
+{
+    yuv_job *j = (yuv_job *)arg;
+    const orc_yuv_consts *k = j->k;
+    const int wi = j->din > 8, wo = j->dout > 8;
+    const int bw = 1 << j->csx, bh = 1 << j->csy;
+    /* one chroma block at a time: bw x bh luma samples share one (Cb,Cr) */
+    for (int by = y0; by < y1; by += bh) {
+        for (int bx = 0; bx < j->w; bx += bw) {
+            const int cx = bx >> j->csx, cy = by >> j->csy;
+            float cbv = (float)ld(j->src[1] + cy * j->ss[1], cx, wi);
+            float crv = (float)ld(j->src[2] + cy * j->ss[2], cx, wi);
+            float rs = 0.f, gs = 0.f, bs = 0.f;
+            if (k->pre) {
+                cbv = clip_floor(fmaf(k->pc, cbv, k->pcb), k->pre_max);
+                crv = clip_floor(fmaf(k->pc, crv, k->pcb), k->pre_max);
+            }
+            const float cb = cbv - k->coff;
+            const float cr = crv - k->coff;
+            const float rv = k->krv * cr;
+            const float gv = fmaf(k->kgu, cb, k->kgv * cr);
+            const float bu = k->kbu * cb;
+            for (int dy = 0; dy < bh; dy++) {
+                /* odd sizes: the edge sample is replicated into the block */
+                const int y = by + dy < j->h ? by + dy : j->h - 1;
+                for (int dx = 0; dx < bw; dx++) {
+                    const int x = bx + dx < j->w ? bx + dx : j->w - 1;
+                    float yv = (float)ld(j->src[0] + y * j->ss[0], x, wi);
+                    int ro, go, bo;
+                    if (k->pre)
+                        yv = clip_floor(fmaf(k->py, yv, k->pyb), k->pre_max);
+                    const float yy = fmaf(k->ky, yv, k->yb);
+                    const float rf = clip_floor(yy + rv, k->max_l);
+                    const float gf = clip_floor(yy + gv, k->max_l);
+                    const float bf = clip_floor(yy + bu, k->max_l);
+                    lut_pixel(j->lut, j->mode, j->lk.scale_f, j->lk.scale_c, j->lk.lut_max,
+                              j->lk.maxf, j->lk.maxi, (int)rf, (int)gf, (int)bf, &ro, &go, &bo);
+                    rs += (float)ro; gs += (float)go; bs += (float)bo;
+                    if (by + dy < j->h && bx + dx < j->w) {
+                        const float yo = clip_floor(
+                            fmaf(k->cyr, (float)ro, fmaf(k->cyg, (float)go, fmaf(k->cyb, (float)bo, k->yob))),
+                            k->max_o);
+                        st(j->dst[0] + y * j->ds[0], x, wo, (int)yo);
+                    }
+                }
+            }
+            {
+                const float cbo = clip_floor(fmaf(k->cbr, rs, fmaf(k->cbg, gs, fmaf(k->cbb, bs, k->cob))), k->max_o);
+                const float cro = clip_floor(fmaf(k->crr, rs, fmaf(k->crg, gs, fmaf(k->crb, bs, k->cob))), k->max_o);
+                st(j->dst[1] + cy * j->ds[1], cx, wo, (int)cbo);
+                st(j->dst[2] + cy * j->ds[2], cx, wo, (int)cro);
+            }
+        }
+    }
+}
+
+int orc_apply_yuv(const orc_lut *lut, int mode, const orc_yuv_consts *k,
+                  int din, int dl, int dout, int csx, int csy, int w, int h,
+                  const void *const src[3], const ptrdiff_t sstride[3],
+                  void *const dst[3], const ptrdiff_t dstride[3], int nthreads)
+{
+    yuv_job j;
+    if (!lut || !lut->rgb || !k || w < 0 || h < 0 || csx < 0 || csx > 1 || csy < 0 || csy > 1 ||
+        din < 8 || din > 16 || dl < 8 || dl > 16 || dout < 8 || dout > 16 ||
+        mode < ORC_NEAREST || mode > ORC_PRISM)
+        return ORC_EINVAL;
+    if (w == 0 || h == 0)
+        return 0;
+    j.lut = lut; j.mode = mode; j.k = k;
+    j.din = din; j.dl = dl; j.dout = dout; j.csx = csx; j.csy = csy; j.w = w; j.h = h;
+    for (int c = 0; c < 3; c++) {
+        j.src[c] = (const uint8_t *)src[c]; j.ss[c] = sstride[c];
+        j.dst[c] = (uint8_t *)dst[c]; j.ds[c] = dstride[c];
+    }
+    make_lut_consts(lut, dl, &j.lk);
+    run_slices(yuv_slice, &j, h, 1 << csy, nthreads);
+    return 0;
+}

@@ -1,0 +1,192 @@
+"""GPU parity: liblutr's HIP kernels (through the C-ABI) against the CPU oracle, bit-exact.
+
+The oracle restates FFmpeg lut3d -- the filter the reference emits at
+/root/reference/src/lut_renderer/ffmpeg.py:246 -- and the engine's YUV contract.  All work
+here is integer codes in / integer codes out, so the bar is exact equality; the <=1 LSB
+(8-bit) / <=2 LSB (10-bit) allowance of the north star is for a live ffmpeg binary
+(tests/test_ffmpeg_live.py), not for our own oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from lut_renderer_amd import cube, frames
+
+pytestmark = pytest.mark.gpu
+
+MODES3 = ("nearest", "trilinear", "tetrahedral")
+MODES5 = MODES3 + ("pyramid", "prism")
+
+
+def _to_dev(planes, eng):
+    out = []
+    for p in planes:
+        t = torch.from_numpy(p.view(np.int16) if p.dtype == np.uint16 else p)
+        out.append(t.to(eng.device))
+    return out
+
+
+def _to_np(tensors, like_dtype):
+    out = []
+    for t in tensors:
+        a = t.cpu().numpy()
+        out.append(a.view(np.uint16) if like_dtype == np.uint16 else a)
+    return out
+
+
+def _load(eng, cube_dir, name):
+    lut = cube.read_cube(cube_dir / name)
+    eng.set_lut(lut)
+    return lut
+
+
+def _assert_equal(got, want, what):
+    for i, (a, b) in enumerate(zip(got, want)):
+        if not np.array_equal(a, b):
+            diff = np.abs(a.astype(np.int64) - b.astype(np.int64))
+            bad = np.argwhere(diff > 0)
+            raise AssertionError(f"{what}: plane {i} differs at {len(bad)} samples, max |d|={diff.max()}, "
+                                 f"first {bad[0].tolist()} got {a[tuple(bad[0])]} want {b[tuple(bad[0])]}")
+
+
+@pytest.mark.parametrize("variant", ["generic", "vec_global"])
+@pytest.mark.parametrize("depth", [8, 10, 12, 16])
+@pytest.mark.parametrize("lutname", ["log709_33.cube", "random_9.cube", "domain_2.cube"])
+def test_rgb_parity(engine, orc, cube_dir, variant, depth, lutname):
+    lut = _load(engine, cube_dir, lutname)
+    engine.set_variant(variant)
+    for dist_k, mk in ((0, frames.uniform_rgb), (1, frames.natural_rgb)):
+        src = mk(128, 36, depth, k=dist_k)
+        for mode in (MODES5 if variant == "generic" else MODES3):
+            want = orc.apply_rgb(lut.table, lut.scale, depth, mode, src)
+            got = _to_np(engine.apply_rgb(_to_dev(src, engine), depth=depth, interp=mode), src[0].dtype)
+            _assert_equal(got, want, f"rgb {variant} d{depth} {mode} {lutname}")
+            assert variant == "generic" or "vec" in engine.last_kernel
+    engine.set_variant("auto")
+
+
+@pytest.mark.parametrize("variant", ["generic", "vec_global"])
+@pytest.mark.parametrize("fmt", ["yuv420p", "yuv420p10le", "yuv422p10le", "yuv444p10le", "yuv422p", "yuv444p",
+                                 "yuv420p12le"])
+def test_yuv_parity(engine, orc, cube_dir, variant, fmt):
+    from lut_renderer_amd.engine import parse_pix_fmt
+    pf = parse_pix_fmt(fmt)
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    engine.set_variant(variant)
+    for matrix, rng_in, rng_out in (("bt709", "tv", "tv"), ("bt2020nc", "tv", "tv"), ("smpte170m", "pc", "tv"),
+                                    ("bt709", "pc", "pc")):
+        k = orc.yuv_constants(matrix, rng_in, matrix, rng_out, pf.depth, None, None, 1 << (pf.csx + pf.csy))
+        for dist in ("uniform", "natural"):
+            src = frames.make_yuv(dist, 128, 36, pf.depth, pf.csx, pf.csy, k=3, full_range=(rng_in == "pc"))
+            for mode in (MODES5 if variant == "generic" else MODES3):
+                want = orc.apply_yuv(lut.table, lut.scale, mode, k, pf.depth, pf.depth, pf.depth, pf.csx, pf.csy, src)
+                got = engine.apply_yuv(_to_dev(src, engine), pix_fmt=fmt, interp=mode, matrix_in=matrix,
+                                       range_src=rng_in, range_out=rng_out)
+                _assert_equal(_to_np(got, src[0].dtype), want, f"yuv {variant} {fmt} {mode} {matrix} {rng_in}->{rng_out} {dist}")
+    engine.set_variant("auto")
+
+
+@pytest.mark.parametrize("w,h", [(2, 2), (6, 4), (31, 17), (130, 7), (1, 1), (33, 2)])
+def test_ragged_sizes_go_generic(engine, orc, cube_dir, w, h):
+    """Odd and tiny sizes (edge chroma blocks replicate the last sample) -- generic kernel."""
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    for fmt, depth, cs in (("yuv420p", 8, (1, 1)), ("yuv420p10le", 10, (1, 1)), ("yuv422p10le", 10, (1, 0))):
+        k = orc.yuv_constants("bt709", "tv", None, "tv", depth, None, None, 1 << sum(cs))
+        src = frames.uniform_yuv(w, h, depth, cs[0], cs[1], k=5)
+        want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, depth, depth, depth, cs[0], cs[1], src)
+        got = engine.apply_yuv(_to_dev(src, engine), pix_fmt=fmt)
+        _assert_equal(_to_np(got, src[0].dtype), want, f"ragged {fmt} {w}x{h}")
+    src = frames.uniform_rgb(w, h, 10, k=6)
+    want = orc.apply_rgb(lut.table, lut.scale, 10, "trilinear", src)
+    got = _to_np(engine.apply_rgb(_to_dev(src, engine), depth=10, interp="trilinear"), np.uint16)
+    _assert_equal(got, want, f"ragged rgb {w}x{h}")
+
+
+def test_empty_inputs_are_noops(engine, cube_dir):
+    _load(engine, cube_dir, "identity_17.cube")
+    z = [torch.empty((0, 16), dtype=torch.uint8, device=engine.device) for _ in range(3)]
+    engine.apply_rgb(z, depth=8)
+    y = [torch.zeros((4, 16), dtype=torch.uint8, device=engine.device),
+         torch.zeros((2, 8), dtype=torch.uint8, device=engine.device),
+         torch.zeros((2, 8), dtype=torch.uint8, device=engine.device)]
+    out = engine.apply_yuv(y, pix_fmt="yuv420p", rows=0)
+    assert out[0].shape == (4, 16)
+
+
+def test_row_shards_and_batches_match_whole_frame(engine, orc, cube_dir):
+    """Row-block shards (the multi-GPU partition) and frame batches give the same pixels."""
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    w, h, nf = 256, 48, 3
+    frames_np = [frames.natural_yuv(w, h, 10, 1, 1, k=i) for i in range(nf)]
+    k = orc.yuv_constants(din=10)
+    want = [orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, f) for f in frames_np]
+    batch = [torch.stack([_to_dev(f, engine)[i] for f in frames_np]) for i in range(3)]
+    got = engine.apply_yuv(batch, pix_fmt="yuv420p10le")
+    for i in range(nf):
+        _assert_equal(_to_np([g[i] for g in got], np.uint16), want[i], f"batch frame {i}")
+    # shard frame 0 into 4 row blocks, even-aligned, applied one by one into one output
+    src = _to_dev(frames_np[0], engine)
+    dst = [torch.zeros_like(t) for t in src]
+    from lut_renderer_amd.shard import row_blocks
+    for r0, r1 in row_blocks(h, 4, align=2):
+        engine.apply_yuv(src, dst, pix_fmt="yuv420p10le", row0=r0, rows=r1 - r0)
+    _assert_equal(_to_np(dst, np.uint16), want[0], "row shards")
+
+
+def test_mixed_depth_and_prologue(engine, orc, cube_dir):
+    """Reference cases K (10-bit LUT, 8-bit output) and A/D (full-range prologue to 8-bit), SURVEY App. D."""
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    # K: yuv420p10le tv source, lut3d at 10 bit, format=yuv420p
+    src = frames.natural_yuv(64, 36, 10, 1, 1, k=9)
+    k = orc.yuv_constants("bt2020nc", "tv", "bt2020nc", "tv", 10, 10, 8, 4)
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 8, 1, 1, src)
+    got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le", out_pix_fmt="yuv420p", matrix_in="bt2020nc")
+    _assert_equal(_to_np(got, np.uint8), want, "case K")
+    # D: yuv422p10le pc source -> scale pc->tv + format=yuv422p (8 bit) -> lut3d -> format=yuv422p10le
+    src = frames.uniform_yuv(64, 36, 10, 1, 0, k=10, full_range=True)
+    k = orc.yuv_constants("smpte170m", "tv", "smpte170m", "tv", 10, 8, 10, 2, prologue=True)
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 8, 10, 1, 0, src)
+    got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv422p10le", matrix_in="smpte170m", range_src="pc",
+                           range_in="tv", lut_depth=8)
+    _assert_equal(_to_np(got, np.uint16), want, "case D")
+    # A: yuvj420p (8-bit pc) -> tv 8 bit -> lut3d
+    src = frames.uniform_yuv(64, 36, 8, 1, 1, k=11, full_range=True)
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", 8, 8, 8, 4, prologue=True)
+    want = orc.apply_yuv(lut.table, lut.scale, "trilinear", k, 8, 8, 8, 1, 1, src)
+    got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p", interp="trilinear", range_src="pc", range_in="tv")
+    _assert_equal(_to_np(got, np.uint8), want, "case A")
+
+
+def test_full_size_properties_uhd(engine, orc, cube_dir):
+    """BASELINE config 2 size (3840x2160 yuv420p10le, 33^3, tetrahedral): properties that need
+    no full-frame oracle run, plus an oracle check on a strip."""
+    w, h = 3840, 2160
+    src_np = frames.natural_yuv(w, h, 10, 1, 1, k=0)
+    src = _to_dev(src_np, engine)
+    # (1) identity lattice: output within 1 code of the input (A.6 #1 composed with the YUV round trip)
+    _load(engine, cube_dir, "identity_33.cube")
+    out = _to_np(engine.apply_yuv(src, pix_fmt="yuv420p10le"), np.uint16)
+    for a, b in zip(out, src_np):
+        assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2
+    # (2) vector kernel == generic kernel on the whole frame (two independent code paths)
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    engine.set_variant("generic")
+    ref = engine.apply_yuv(src, pix_fmt="yuv420p10le")
+    engine.set_variant("auto")
+    fast = engine.apply_yuv(src, pix_fmt="yuv420p10le")
+    assert "vec" in engine.last_kernel
+    for a, b in zip(ref, fast):
+        assert torch.equal(a, b)
+    # (3) idempotence of sharding: 8 row blocks == whole frame
+    from lut_renderer_amd.shard import row_blocks
+    dst = [torch.zeros_like(t) for t in src]
+    for r0, r1 in row_blocks(h, 8, align=2):
+        engine.apply_yuv(src, dst, pix_fmt="yuv420p10le", row0=r0, rows=r1 - r0)
+    for a, b in zip(dst, fast):
+        assert torch.equal(a, b)
+    # (4) oracle on a 64-row strip of the same frame
+    strip = [src_np[0][512:576], src_np[1][256:288], src_np[2][256:288]]
+    k = orc.yuv_constants(din=10)
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, strip, nthreads=8)
+    got = _to_np(fast, np.uint16)
+    _assert_equal([got[0][512:576], got[1][256:288], got[2][256:288]], want, "uhd strip")
