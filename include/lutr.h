@@ -125,7 +125,9 @@ void lutr_cube_free(float *rgb);
 /* ---- context ---- */
 int  lutr_ctx_create(int device, lutr_ctx **out);
 void lutr_ctx_destroy(lutr_ctx *ctx);
-/* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the context's own stream */
+/* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL selects HIP's default
+ * (null) stream, which is what torch.cuda.current_stream() is unless the caller changed it.
+ * Until this is called the context uses a private non-blocking stream. */
 int  lutr_ctx_set_stream(lutr_ctx *ctx, void *hip_stream);
 int  lutr_ctx_sync(lutr_ctx *ctx);
 

@@ -234,7 +234,7 @@ void lutr_ctx_destroy(lutr_ctx *c)
 int lutr_ctx_set_stream(lutr_ctx *c, void *hip_stream)
 {
     if (!c) { set_error("null context"); return LUTR_EINVAL; }
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;   // NULL is HIP's default (null) stream, e.g. torch's default
     return LUTR_OK;
 }
 
