@@ -182,6 +182,13 @@ def main():
 
     wall, kern = time_steps(eng, src, dst, args.fmt, args.interp, args.steps, args.warmup, world)
     kernel_name = eng.last_kernel
+    tile_stats = None
+    if "tile" in kernel_name:                    # one extra, untimed pass with the window counters armed
+        eng.tile_stats(True)
+        eng.apply_yuv(src, dst, pix_fmt=args.fmt, interp=args.interp)
+        tile_stats = eng.tile_stats(False)
+        if rank == 0:
+            log(f"[tile stats] {tile_stats}")
     t = torch.tensor([wall, kern, float(px_rank)], dtype=torch.float64, device=eng.device)
     if world > 1:
         import torch.distributed as dist
@@ -200,7 +207,10 @@ def main():
                 s2 = build_batch(eng, pf, w, h, r0, r1, nframes, dname, args.unique)
                 _, k2 = time_steps(eng, s2, dst, args.fmt, mode, max(3, args.steps // 2), 2, 1)
                 extra[f"{dname}/{mode}"] = round(px_rank / k2 / 1e6, 1)
-                log(f"[extra] {dname:8s} {mode:12s} {extra[f'{dname}/{mode}']:>12.1f} Mpx/s  ({eng.last_kernel})")
+                eng.tile_stats(True)
+                eng.apply_yuv(s2, dst, pix_fmt=args.fmt, interp=mode)
+                log(f"[extra] {dname:8s} {mode:12s} {extra[f'{dname}/{mode}']:>12.1f} Mpx/s  ({eng.last_kernel}) "
+                    f"{eng.tile_stats(False)}")
                 del s2
 
     if rank == 0:
@@ -227,7 +237,7 @@ def main():
                 "workload": f"{w}x{h} {args.fmt}, {args.lut}^3 log->Rec.709 .cube, {args.interp}, "
                             f"{args.frames} frames/GPU/step resident in HBM, row-block shard x{world}",
                 "frames_per_gpu": args.frames, "lut_size": args.lut, "interp": args.interp,
-                "pix_fmt": args.fmt, "distribution": args.dist, "kernel": kernel_name,
+                "pix_fmt": args.fmt, "distribution": args.dist, "kernel": kernel_name, "lds_window": tile_stats,
                 "parallelism": f"row-block x{world}", "bytes_per_pixel": bpp,
             },
             "roofline": {

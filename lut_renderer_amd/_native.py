@@ -27,7 +27,7 @@ SYMBOLS = (
     "lutr_ctx_create", "lutr_ctx_destroy", "lutr_ctx_set_stream", "lutr_ctx_sync",
     "lutr_ctx_set_lut", "lutr_ctx_lut_alloc", "lutr_ctx_lut_device", "lutr_lattice_bytes",
     "lutr_apply_planar_rgb", "lutr_apply_yuv",
-    "lutr_ctx_set_variant", "lutr_ctx_last_kernel", "lutr_yuv_constants",
+    "lutr_ctx_set_variant", "lutr_ctx_last_kernel", "lutr_ctx_tile_stats", "lutr_yuv_constants",
 )
 
 
@@ -90,6 +90,7 @@ def load() -> C.CDLL:
     lib.lutr_ctx_set_variant.argtypes = [vp, ci]
     lib.lutr_ctx_last_kernel.argtypes = [vp]
     lib.lutr_ctx_last_kernel.restype = cp
+    lib.lutr_ctx_tile_stats.argtypes = [vp, ci, C.POINTER(C.c_uint64)]
     lib.lutr_yuv_constants.argtypes = [C.POINTER(YuvParams), C.POINTER(C.c_float)]
     _lib = lib
     return lib

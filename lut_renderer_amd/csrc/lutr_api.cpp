@@ -164,6 +164,7 @@ struct lutr_ctx {
     float scale[3] = {1.f, 1.f, 1.f};
     int variant = VAR_AUTO;
     std::string last_kernel;
+    unsigned *stats = nullptr;       // 4 device counters, allocated by lutr_ctx_tile_stats_enable
 };
 
 extern "C" {
@@ -227,6 +228,7 @@ void lutr_ctx_destroy(lutr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->lat) (void)hipFree(c->lat);
+    if (c->stats) (void)hipFree(c->stats);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -257,6 +259,30 @@ int lutr_ctx_set_variant(lutr_ctx *c, int variant)
 }
 
 const char *lutr_ctx_last_kernel(lutr_ctx *c) { return c ? c->last_kernel.c_str() : ""; }
+
+int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[4])
+{
+    if (!c) { set_error("null context"); return LUTR_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (out) {
+        for (int i = 0; i < 4; i++) out[i] = 0;
+        if (c->stats) {
+            unsigned h[4];
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 4; i++) out[i] = h[i];
+        }
+    }
+    if (enable && !c->stats) {
+        HIP_TRY(hipMalloc((void **)&c->stats, 4 * sizeof(unsigned)));
+    } else if (!enable && c->stats) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->stats);
+        c->stats = nullptr;
+    }
+    if (c->stats) HIP_TRY(hipMemset(c->stats, 0, 4 * sizeof(unsigned)));
+    return LUTR_OK;
+}
 
 static int alloc_lattice(lutr_ctx *c, int n, const float scale[3])
 {
@@ -390,7 +416,7 @@ int lutr_apply_planar_rgb(lutr_ctx *c, int depth, int interp, int w, int h, int 
     LutConsts L; PlaneSet P; FrameGeom G{w, h, row0, rows, nframes};
     fill_lut(&L, c, depth);
     fill_planes(&P, src, dst);
-    return finish_launch(c, launch_rgb(c->stream, c->variant, L, P, G, depth, interp));
+    return finish_launch(c, launch_rgb(c->stream, c->variant, L, P, G, depth, interp, c->stats));
 }
 
 int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int h, int nframes,
@@ -416,7 +442,7 @@ int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int
     fill_lut(&L, c, p->lut_depth);
     fill_planes(&P, src, dst);
     return finish_launch(c, launch_yuv(c->stream, c->variant, L, K, P, G, LUTR_FMT_DEPTH(p->fmt_in),
-                                       LUTR_FMT_DEPTH(p->fmt_out), csx, csy, interp));
+                                       LUTR_FMT_DEPTH(p->fmt_out), csx, csy, interp, c->stats));
 }
 
 }  // extern "C"

@@ -30,10 +30,10 @@ struct GFetch {
     int   sr, sg;   // the same as ints
     __device__ __forceinline__ explicit GFetch(const LutConsts &L)
         : lat(L.lat), fr((float)(L.n1 * L.n1)), fg((float)L.n1), sr(L.n1 * L.n1), sg(L.n1) {}
-    // exact: all three terms are integers below 2^24 (n1 <= 257)
+    // integer math: n1^3 reaches 2^24 at N = 256, one step past what fp32 holds exactly
     __device__ __forceinline__ int index(float pr, float pg, float pb) const
     {
-        return (int)fma_(pr, fr, fma_(pg, fg, pb));
+        return ((int)pr * sg + (int)pg) * sg + (int)pb;
     }
     __device__ __forceinline__ float4 ld(int i) const { return lat[i]; }
 };
@@ -458,7 +458,7 @@ static unsigned grid_for(long long units, unsigned cap = 0x7fffffffu)
 }
 
 const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const PlaneSet &P,
-                       const FrameGeom &G, int depth, int mode)
+                       const FrameGeom &G, int depth, int mode, unsigned *stats)
 {
     const int wide = depth > 8;
     const int pxt = wide ? 8 : 16;
@@ -468,6 +468,8 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     for (int c = 0; c < 3 && vec_ok; c++)
         vec_ok = planes_aligned(P, c, 16, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
+    if (vec_ok && (variant == VAR_AUTO || variant == VAR_VEC_LDS))
+        return launch_rgb_tile(st, L, P, G, depth, mode, stats);
     if (!vec_ok) {
         if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
         // grid-stride; enough blocks to fill 256 CUs x 8
@@ -487,7 +489,8 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
 }
 
 const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const YuvConsts &K,
-                       const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy, int mode)
+                       const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy, int mode,
+                       unsigned *stats)
 {
     const int win = din > 8, wout = dout > 8;
     const int pxt = win ? 8 : 16;
@@ -500,6 +503,8 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     if (vec_ok) vec_ok = planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, cbytes, G.nframes > 1) &&
                          planes_aligned(P, 2, cbytes, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
+    if (vec_ok && (variant == VAR_AUTO || variant == VAR_VEC_LDS))
+        return launch_yuv_tile(st, L, K, P, G, win, csx, csy, mode, stats);
     if (!vec_ok) {
         if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
         const long long blocks = (long long)((G.w + (1 << csx) - 1) >> csx) * ((G.rows + bh - 1) >> csy) * G.nframes;

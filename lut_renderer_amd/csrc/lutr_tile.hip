@@ -1,0 +1,680 @@
+// lutr_tile.hip -- the fast path: persistent waves with a per-wave LDS lattice window.
+//
+// Replaces the slice-threaded per-row loops of FFmpeg's lut3d + the scalers around it
+// (the filters /root/reference/src/lut_renderer/ffmpeg.py:212-247,:304-310 emits).
+//
+// Design (DESIGN.md "Kernels"):
+//   * A 33^3 fp32 lattice (431 KB; 629 KB as padded float4) does not fit the 160 KB LDS,
+//     and gathering 4-8 taps of 16 B per pixel from L1/L2 caps at ~1 px/clk/CU.  Video
+//     pixels that are close on screen are close in colour, so each WAVE keeps a small
+//     WINDOW of the lattice in LDS and reads its taps with ds_read_b128 (broadcast when
+//     neighbouring lanes share a cell).
+//   * The window is a box in SHEARED lattice coordinates (r, g-r, b-r): luma moves a
+//     colour along the cube's diagonal (one long axis), chroma across it (two short
+//     axes).  A box that is long in r and 4..16 nodes wide in the other two covers a
+//     tile with a dark-to-bright edge where an axis-aligned RGB box of the same size
+//     could not.
+//   * Lookups are OPTIMISTIC: a tile is computed against whatever window the wave holds
+//     while per-lane min/max of the cell coordinates are accumulated; one wave vote at
+//     the end of the tile says whether every tap was inside.  Only on a miss are the
+//     bounds reduced across the wave, the window re-staged from L2 (or, if the tile's
+//     colours do not fit, the tile routed to the global-gather body) and the tile redone.
+//     Waves walk DOWN a column strip, so consecutive tiles mostly hit.
+//   * No workgroup barrier anywhere: waves are independent; a wave's only shared state
+//     is its own LDS slice.
+//
+// Arithmetic is the strict restatement (see lutr_kernels.hip): -ffp-contract=off, FFmpeg's
+// scalar C order, bit-identical to the oracle.
+#include <cstdlib>
+
+#include "lutr_internal.h"
+
+namespace lutr {
+
+extern __shared__ __attribute__((aligned(16))) char lutr_smem[];
+
+// ---------------------------------------------------------------- small math
+__device__ __forceinline__ float tmed3(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
+__device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- window state (wave-uniform)
+struct Win {
+    // byte address of the tap at cell (pr,pg,pb): (int) fma(pr, fr, fma(pg, fg, fma(pb, fb, fc)))
+    float fr, fg, fb, fc;
+    int   o_r, o_g, o_b;                          // byte steps of +1 along r, g, b
+    unsigned a_max;                               // LDS only: highest base address whose 8 corners stay inside
+                                                  // the workgroup's allocation (optimistic reads never leave it)
+    float r_lo, r_hi, g_lo, g_hi, b_lo, b_hi;     // cells (pr, pg-pr, pb-pr) whose 8 corners are staged
+};
+
+struct Bnd { float rmin, rmax, gmin, gmax, bmin, bmax; };
+
+__device__ __forceinline__ void bnd_reset(Bnd &b)
+{
+    b.rmin = b.gmin = b.bmin = 1e9f;
+    b.rmax = b.gmax = b.bmax = -1e9f;
+}
+
+// A node is read as one 16-byte access.  The empty (non-volatile, zero-instruction) asm makes
+// .x depend on .w, so hipcc cannot narrow the LDS read to ds_read_b96 just because .w is
+// padding: b96 costs 8 LDS cycles per wave-instruction, b128 costs 4 (MI355X_MICROARCH.md, LDS).
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <bool LDS>
+__device__ __forceinline__ f4 tap(const float4 *__restrict__ lat, int a)
+{
+    if constexpr (LDS) {
+        f4 v = *(const f4 *)(lutr_smem + a);
+        float x = v.x, w = v.w;
+        asm("" : "+v"(x) : "v"(w));
+        v.x = x;
+        return v;
+    } else {
+        return *(const f4 *)((const char *)lat + a);
+    }
+}
+
+struct Rgb3 { float r, g, b; };
+
+__device__ __forceinline__ float tlerp(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
+
+// One pixel of SURVEY A.3-A.5 against window W.  Integer codes in (as floats), integer
+// codes out (as floats).  Accumulates the cell bounds the window check needs.
+template <bool LDS, int INTERP>
+__device__ __forceinline__ Rgb3 lut_px(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
+{
+    const float xr = rc * L.scale_f, xg = gc * L.scale_f, xb = bc * L.scale_f;
+    const float sr = tmed3(xr * L.sc[0], 0.0f, L.lut_max);
+    const float sg = tmed3(xg * L.sc[1], 0.0f, L.lut_max);
+    const float sb = tmed3(xb * L.sc[2], 0.0f, L.lut_max);
+    float pr, pg, pb;
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) {
+        pr = floorf(sr + .5f); pg = floorf(sg + .5f); pb = floorf(sb + .5f);
+    } else {
+        pr = floorf(sr); pg = floorf(sg); pb = floorf(sb);
+    }
+    {   // bounds in sheared coordinates
+        const float hg = pg - pr, hb = pb - pr;
+        bn.rmin = fminf(bn.rmin, pr); bn.rmax = fmaxf(bn.rmax, pr);
+        bn.gmin = fminf(bn.gmin, hg); bn.gmax = fmaxf(bn.gmax, hg);
+        bn.bmin = fminf(bn.bmin, hb); bn.bmax = fmaxf(bn.bmax, hb);
+    }
+    int a;
+    if constexpr (LDS) {
+        // exact in fp32: every term is an integer well below 2^24 for a window of <= 4096 nodes
+        a = (int)tfma(pr, W.fr, tfma(pg, W.fg, tfma(pb, W.fb, W.fc)));
+        a = (int)min((unsigned)a, W.a_max);       // a stale window may not contain this cell: stay in LDS
+    } else {
+        a = (((int)pr * L.n1 + (int)pg) * L.n1 + (int)pb) * 16;
+    }
+    Rgb3 v;
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) {
+        const f4 c = tap<LDS>(L.lat, a);
+        v.r = c.x; v.g = c.y; v.b = c.z;
+    } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
+        const float dr = sr - pr, dg = sg - pg, db = sb - pb;
+        const f4 c000 = tap<LDS>(L.lat, a), c001 = tap<LDS>(L.lat, a + W.o_b);
+        const f4 c010 = tap<LDS>(L.lat, a + W.o_g), c011 = tap<LDS>(L.lat, a + W.o_g + W.o_b);
+        const f4 c100 = tap<LDS>(L.lat, a + W.o_r), c101 = tap<LDS>(L.lat, a + W.o_r + W.o_b);
+        const f4 c110 = tap<LDS>(L.lat, a + W.o_r + W.o_g), c111 = tap<LDS>(L.lat, a + W.o_r + W.o_g + W.o_b);
+#define TRI(ch, out) \
+        { \
+            const float c00 = tlerp(c000.ch, c100.ch, dr), c10 = tlerp(c010.ch, c110.ch, dr); \
+            const float c01 = tlerp(c001.ch, c101.ch, dr), c11 = tlerp(c011.ch, c111.ch, dr); \
+            const float c0 = tlerp(c00, c10, dg), c1 = tlerp(c01, c11, dg); \
+            out = tlerp(c0, c1, db); \
+        }
+        TRI(x, v.r) TRI(y, v.g) TRI(z, v.b)
+#undef TRI
+    } else {
+        // tetrahedral, sorted form (see lutr_kernels.hip interp_tetrahedral for why this is
+        // bit-identical to FFmpeg's six branches on a finite lattice)
+        const float dr = sr - pr, dg = sg - pg, db = sb - pb;
+        const float x = fmaxf(fmaxf(dr, dg), db), y = tmed3(dr, dg, db), z = fminf(fminf(dr, dg), db);
+        const bool rg = dr > dg, gb = dg > db, rb = dr > db;
+        // by-value copies: a ?: over struct members is an lvalue select, which pins W in scratch
+        const int o_r = W.o_r, o_g = W.o_g, o_b = W.o_b;
+        const int o111 = o_r + o_g + o_b;
+        const int z_r = o111 - o_r, z_g = o111 - o_g, z_b = o111 - o_b;
+        // first step along the axis of the largest fraction, last step along the smallest
+        const int oa = (rg && rb) ? o_r : ((!rg && gb) ? o_g : o_b);
+        const int oz = (gb && rb) ? z_b : ((!gb && rg) ? z_g : z_r);
+        const f4 c0 = tap<LDS>(L.lat, a), c1 = tap<LDS>(L.lat, a + oa);
+        const f4 c2 = tap<LDS>(L.lat, a + oz), c3 = tap<LDS>(L.lat, a + o111);
+        const float w0 = 1.0f - x, w1 = x - y, w2 = y - z, w3 = z;
+        v.r = w0 * c0.x + w1 * c1.x + w2 * c2.x + w3 * c3.x;
+        v.g = w0 * c0.y + w1 * c1.y + w2 * c2.y + w3 * c3.y;
+        v.b = w0 * c0.z + w1 * c1.z + w2 * c2.z + w3 * c3.z;
+    }
+    Rgb3 o;
+    o.r = tmed3(truncf(v.r * L.maxf), 0.0f, L.maxf);
+    o.g = tmed3(truncf(v.g * L.maxf), 0.0f, L.maxf);
+    o.b = tmed3(truncf(v.b * L.maxf), 0.0f, L.maxf);
+    return o;
+}
+
+// ---------------------------------------------------------------- window management
+__device__ __forceinline__ void win_global(Win &W, const LutConsts &L)
+{
+    const int n1 = L.n1;
+    W.fr = W.fg = W.fb = W.fc = 0.0f;             // unused: the global body addresses with integers
+    W.o_r = 16 * n1 * n1; W.o_g = 16 * n1; W.o_b = 16;
+    W.a_max = 0;
+    W.r_lo = W.g_lo = W.b_lo = 1.0f;
+    W.r_hi = W.g_hi = W.b_hi = 0.0f;
+}
+
+// No window staged yet: every tap of an optimistic pass reads the first node of the slice
+// (harmless), and the admissible set is empty so the pass is always declared a miss.
+__device__ __forceinline__ void win_empty(Win &W, int slice_off)
+{
+    W.fr = W.fg = W.fb = 0.0f; W.fc = (float)slice_off;
+    W.o_r = W.o_g = W.o_b = 0;
+    W.a_max = (unsigned)slice_off;
+    W.r_lo = W.g_lo = W.b_lo = 1.0f;
+    W.r_hi = W.g_hi = W.b_hi = 0.0f;
+}
+
+__device__ __forceinline__ bool win_holds(const Win &W, const Bnd &b)
+{
+    const bool ok = b.rmin >= W.r_lo && b.rmax <= W.r_hi && b.gmin >= W.g_lo && b.gmax <= W.g_hi &&
+                    b.bmin >= W.b_lo && b.bmax <= W.b_hi;
+    return __all(ok);
+}
+
+// Reduce the tile's bounds over the wave and, if a window of `cap` nodes can hold every
+// corner the tile touches PLUS one spare cell on each side of the two chroma-like axes (sensor
+// noise moves the extremes by a cell from tile to tile; without the spare every other tile
+// misses), stage it into this wave's LDS slice and describe it in W.  The r axis takes the
+// rest of the capacity, centred.  Returns false (W untouched) when the tile's colours are too
+// spread out for the slice.
+__device__ __forceinline__ bool win_restage(Win &W, const LutConsts &L, const Bnd &bn, int cap, int slice_off,
+                                            int lds_bytes, int lane)
+{
+    const int rmin = uni((int)wave_min(bn.rmin)), rmax = uni((int)wave_max(bn.rmax));
+    const int gmin = uni((int)wave_min(bn.gmin)), gmax = uni((int)wave_max(bn.gmax));
+    const int bmin = uni((int)wave_min(bn.bmin)), bmax = uni((int)wave_max(bn.bmax));
+    // corners: r..r+1, (g-r)-1..(g-r)+1, (b-r)-1..(b-r)+1
+    const int need_r = rmax - rmin + 2, need_g = gmax - gmin + 3, need_b = bmax - bmin + 3;
+    int ng = need_g + 2, nb = need_b + 2;                    // one spare cell each side
+    int sr = (ng * nb) | 1;                                   // odd plane stride: r-neighbours hit different banks
+    if (need_r + 2 > cap / sr) { ng = need_g; nb = need_b; sr = (ng * nb) | 1; }   // no room for spares
+    const int nr = cap / sr;
+    if (need_r > nr || ng > 128 || nb > 128) return false;
+    const int r0 = rmin - ((nr - need_r) >> 1);
+    const int g0 = gmin - 1 - ((ng - need_g) >> 1);
+    const int b0 = bmin - 1 - ((nb - need_b) >> 1);
+    const int n1 = L.n1, nmax = L.n1 - 1;
+    const int plane = ng * nb, total = nr * plane;
+    // i -> (ir, ig, ib): floor(i/d) = umulhi(i, ceil(2^32/d)), exact while i*d < 2^32 (i < 8192, d <= 16641)
+    const unsigned inv_plane = (unsigned)((0x100000000ull + plane - 1) / plane);
+    const unsigned inv_nb = (unsigned)((0x100000000ull + nb - 1) / nb);
+    for (int i = lane; i < total; i += 64) {
+        const int ir = (int)__umulhi((unsigned)i, inv_plane), rem = i - ir * plane;
+        const int ig = (int)__umulhi((unsigned)rem, inv_nb), ib = rem - ig * nb;
+        int r = r0 + ir, g = r + g0 + ig, b = r + b0 + ib;
+        // nodes outside the cube are never referenced by a valid pixel: clamp to stay in bounds
+        r = min(max(r, 0), nmax); g = min(max(g, 0), nmax); b = min(max(b, 0), nmax);
+        const float4 v = L.lat[(r * n1 + g) * n1 + b];
+        *(float4 *)(lutr_smem + slice_off + 16 * (ir * sr + ig * nb + ib)) = v;
+    }
+    // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pr-b0)
+    W.o_r = 16 * (sr - nb - 1); W.o_g = 16 * nb; W.o_b = 16;
+    W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = 16.0f;
+    W.fc = (float)(slice_off - 16 * (r0 * sr + g0 * nb + b0));
+    W.a_max = (unsigned)(lds_bytes - (W.o_r + W.o_g + W.o_b) - 16);
+    W.r_lo = (float)r0;       W.r_hi = (float)(r0 + nr - 2);
+    W.g_lo = (float)(g0 + 1); W.g_hi = (float)(g0 + ng - 2);
+    W.b_lo = (float)(b0 + 1); W.b_hi = (float)(b0 + nb - 2);
+    return true;
+}
+
+// optional per-launch statistics (tests, tuning): [0] tiles, [1] LDS passes that missed,
+// [2] tiles computed by the global-gather body, [3] windows staged
+__device__ __forceinline__ void stat_add(unsigned *stats, int which, int lane)
+{
+    if (stats && lane == 0) atomicAdd(&stats[which], 1u);
+}
+
+// ---------------------------------------------------------------- sample helpers
+template <int WIDE>
+__device__ __forceinline__ float wsample(const uint32_t *w, int i)
+{
+    if constexpr (WIDE) return (float)((w[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+    else return (float)((w[i >> 2] >> ((i & 3) * 8)) & 0xffu);
+}
+
+template <int WIDE>
+__device__ __forceinline__ void wput(uint32_t *w, int i, float v)
+{
+    const uint32_t u = (uint32_t)v;
+    if constexpr (WIDE) w[i >> 1] |= u << ((i & 1) * 16);
+    else w[i >> 2] |= u << ((i & 3) * 8);
+}
+
+template <int NW>
+__device__ __forceinline__ void ldw(uint32_t *w, const uint8_t *p)
+{
+    if constexpr (NW == 4) { const uint4 v = *(const uint4 *)p; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else { const uint2 v = *(const uint2 *)p; w[0] = v.x; w[1] = v.y; }
+}
+
+template <int NW>
+__device__ __forceinline__ void stw(uint8_t *p, const uint32_t *w)
+{
+    if constexpr (NW == 4) *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]);
+    else *(uint2 *)p = make_uint2(w[0], w[1]);
+}
+
+// Zero-instruction ordering fence.  hipcc's instruction selection linearises an unrolled block
+// with every pure computation first, which keeps the coordinates and weights of all 16 pixels
+// of a unit live at once (>1000 spilled registers).  Passing the not-yet-consumed input words
+// and the partly built output words through volatile asm statements makes group j+1's inputs
+// unknowable until group j's outputs exist, so pixel groups are emitted one after the other.
+template <int N>
+__device__ __forceinline__ void fence_words(uint32_t *w)
+{
+    if constexpr (N == 1) asm volatile("" : "+v"(w[0]));
+    else if constexpr (N == 2) asm volatile("" : "+v"(w[0]), "+v"(w[1]));
+    else if constexpr (N == 4) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    else if constexpr (N == 8) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+}
+
+__device__ __forceinline__ float cfloor(float v, float hi) { return tmed3(floorf(v), 0.0f, hi); }
+
+// ---------------------------------------------------------------- tile geometry
+struct TileGeom {
+    int lw_log2;          // lanes along x per tile row = 1 << lw_log2 (the other lanes go down)
+    int uw, urows;        // units per row, unit rows (a unit = PXT px x BH rows)
+    int nsx, nry;         // tiles across, tiles down
+    int tiles;            // nframes * nsx * nry
+    int tiles_per_wave;
+    int win_nodes;        // LDS window capacity per wave, in 16-byte nodes
+    unsigned *stats;      // optional device counters (see stat_add); nullptr = off
+};
+
+// ================================================================= fused YUV tile kernel
+template <int WIDE, int CSX, int CSY>
+struct YuvTile {
+    static constexpr int PXT = WIDE ? 8 : 16;
+    static constexpr int BH = 1 << CSY, BW = 1 << CSX;
+    static constexpr int NC = PXT >> CSX;
+    static constexpr int CW = NC * (WIDE ? 2 : 1) / 4;
+    uint32_t y[BH][4], cb[CW], cr[CW];
+};
+
+template <bool LDS, int WIDE, int CSX, int CSY, int INTERP>
+__device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConsts &K, const Win &W,
+                                              const YuvTile<WIDE, CSX, CSY> &in_, YuvTile<WIDE, CSX, CSY> &out, Bnd &bn)
+{
+    using T = YuvTile<WIDE, CSX, CSY>;
+    T in = in_;
+#pragma unroll
+    for (int dy = 0; dy < T::BH; dy++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) out.y[dy][k] = 0;
+#pragma unroll
+    for (int k = 0; k < T::CW; k++) { out.cb[k] = 0; out.cr[k] = 0; }
+    const bool pre = K.pre != 0.0f;
+#pragma unroll
+    for (int j = 0; j < T::NC; j++) {
+        float cbv = wsample<WIDE>(in.cb, j), crv = wsample<WIDE>(in.cr, j);
+        if (pre) {
+            cbv = cfloor(tfma(K.pc, cbv, K.pcb), K.pre_max);
+            crv = cfloor(tfma(K.pc, crv, K.pcb), K.pre_max);
+        }
+        const float cbd = cbv - K.coff, crd = crv - K.coff;
+        const float rv = K.krv * crd, gv = tfma(K.kgu, cbd, K.kgv * crd), bu = K.kbu * cbd;
+        float rs = 0.f, gs = 0.f, bs = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < T::BH; dy++) {
+#pragma unroll
+            for (int dx = 0; dx < T::BW; dx++) {
+                const int i = j * T::BW + dx;
+                float yv = wsample<WIDE>(in.y[dy], i);
+                if (pre) yv = cfloor(tfma(K.py, yv, K.pyb), K.pre_max);
+                const float yy = tfma(K.ky, yv, K.yb);
+                const float rq = cfloor(yy + rv, K.max_l), gq = cfloor(yy + gv, K.max_l), bq = cfloor(yy + bu, K.max_l);
+                const Rgb3 o = lut_px<LDS, INTERP>(L, W, rq, gq, bq, bn);
+                rs += o.r; gs += o.g; bs += o.b;
+                wput<WIDE>(out.y[dy], i, cfloor(tfma(K.cyr, o.r, tfma(K.cyg, o.g, tfma(K.cyb, o.b, K.yob))), K.max_o));
+            }
+        }
+        wput<WIDE>(out.cb, j, cfloor(tfma(K.cbr, rs, tfma(K.cbg, gs, tfma(K.cbb, bs, K.cob))), K.max_o));
+        wput<WIDE>(out.cr, j, cfloor(tfma(K.crr, rs, tfma(K.crg, gs, tfma(K.crb, bs, K.cob))), K.max_o));
+        // emit the unit group by group (see fence_words)
+        fence_words<4 * T::BH>(&in.y[0][0]);
+        fence_words<T::CW>(in.cb);
+        fence_words<T::CW>(in.cr);
+        fence_words<4 * T::BH>(&out.y[0][0]);
+        fence_words<T::CW>(out.cb);
+        fence_words<T::CW>(out.cr);
+    }
+}
+
+// 3 waves per SIMD: the unit's live set is ~160 VGPRs; capping at 128 (4 waves) spills into the
+// hot loop and is slower (measured: 214-245 vs 249-253 Gpx/s on UHD yuv420p10le tetrahedral).
+#ifndef LUTR_TILE_WAVES_PER_EU
+#define LUTR_TILE_WAVES_PER_EU 3
+#endif
+
+template <int WIDE, int CSX, int CSY, int INTERP>
+__global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
+void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
+{
+    using T = YuvTile<WIDE, CSX, CSY>;
+    const int lane = threadIdx.x & 63;
+    const int wib = uni(threadIdx.x >> 6);
+    const int wave = blockIdx.x * 4 + wib;
+    int t = uni(wave * TG.tiles_per_wave);
+    const int t_end = uni(min(t + TG.tiles_per_wave, TG.tiles));
+    if (t >= t_end) return;                                   // wave-uniform; no barrier is ever used
+    const int slice_off = wib * TG.win_nodes * 16;
+
+    // tile id -> (frame, strip, tile row); consecutive ids walk DOWN a strip
+    int fr = t / (TG.nsx * TG.nry);
+    int rem = t - fr * (TG.nsx * TG.nry);
+    int sx = rem / TG.nry, ry = rem - sx * TG.nry;
+    const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
+    const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
+    const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
+
+    const int lds_bytes = 4 * TG.win_nodes * 16;
+    Win W, WG;
+    win_empty(W, slice_off);
+    win_global(WG, L);
+    bool lds_mode = true;                                     // optimistic; the first tile misses and stages
+    constexpr int CWB = T::CW * 4;
+
+    // Input words of a tile.  Idle lanes of edge tiles re-read a valid unit of the same tile.
+    auto load_tile = [&](T &dst, int f, int tsx, int try_) {
+        const int lxc = min(lx, TG.uw - 1 - tsx * lw), lyc = min(ly, TG.urows - 1 - (try_ << lh_log2));
+        const long long urow0 = cr0 + (try_ << lh_log2);                  // wave-uniform
+        const uint8_t *sy = P.s[0] + f * P.sfs[0] + urow0 * T::BH * P.ss[0] + (long long)tsx * lw * 16;
+        const uint8_t *scb = P.s[1] + f * P.sfs[1] + urow0 * P.ss[1] + (long long)tsx * lw * CWB;
+        const uint8_t *scr = P.s[2] + f * P.sfs[2] + urow0 * P.ss[2] + (long long)tsx * lw * CWB;
+#pragma unroll
+        for (int dy = 0; dy < T::BH; dy++)
+            ldw<4>(dst.y[dy], sy + (unsigned)((lyc * T::BH + dy) * (int)P.ss[0] + lxc * 16));
+        ldw<T::CW>(dst.cb, scb + (unsigned)(lyc * (int)P.ss[1] + lxc * CWB));
+        ldw<T::CW>(dst.cr, scr + (unsigned)(lyc * (int)P.ss[2] + lxc * CWB));
+    };
+
+    T nxt;
+    load_tile(nxt, fr, sx, ry);
+    for (; t < t_end; t++) {
+        const T in = nxt;
+        const int cfr = fr, csx = sx, cry = ry;
+        // advance to the next tile and issue its loads NOW: vmcnt retires in order, so loads issued
+        // after this tile's stores would wait for those stores to be acknowledged by HBM
+        if (++ry == TG.nry) {
+            ry = 0;
+            if (++sx == TG.nsx) { sx = 0; fr++; }
+        }
+        if (t + 1 < t_end) load_tile(nxt, fr, sx, ry);
+
+        T out;
+        Bnd bn;
+        for (;;) {
+            bnd_reset(bn);
+            if (lds_mode) {
+                yuv_tile_body<true, WIDE, CSX, CSY, INTERP>(L, K, W, in, out, bn);
+                if (win_holds(W, bn)) break;
+                // miss: re-stage around this tile's colours and redo it, or give the tile to the gather body
+                stat_add(TG.stats, 1, lane);
+                if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
+                else stat_add(TG.stats, 3, lane);
+            } else {
+                yuv_tile_body<false, WIDE, CSX, CSY, INTERP>(L, K, WG, in, out, bn);
+                stat_add(TG.stats, 2, lane);
+                // colours narrow enough again?  then the next tile starts from a staged window
+                if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; stat_add(TG.stats, 3, lane); }
+                break;
+            }
+        }
+        {
+            const int xu = csx * lw + lx, yu = (cry << lh_log2) + ly;
+            const bool active = xu < TG.uw && yu < TG.urows;
+            const long long urow0 = cr0 + (cry << lh_log2);
+            uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * P.ds[0] + (long long)csx * lw * 16;
+            uint8_t *dcb = P.d[1] + cfr * P.dfs[1] + urow0 * P.ds[1] + (long long)csx * lw * CWB;
+            uint8_t *dcr = P.d[2] + cfr * P.dfs[2] + urow0 * P.ds[2] + (long long)csx * lw * CWB;
+            if (active) {
+#pragma unroll
+                for (int dy = 0; dy < T::BH; dy++)
+                    stw<4>(dy_ + (unsigned)((ly * T::BH + dy) * (int)P.ds[0] + lx * 16), out.y[dy]);
+                stw<T::CW>(dcb + (unsigned)(ly * (int)P.ds[1] + lx * CWB), out.cb);
+                stw<T::CW>(dcr + (unsigned)(ly * (int)P.ds[2] + lx * CWB), out.cr);
+            }
+        }
+        stat_add(TG.stats, 0, lane);
+    }
+}
+
+// ================================================================= planar RGB tile kernel
+template <int WIDE>
+struct RgbTile {
+    static constexpr int PXT = WIDE ? 8 : 16;
+    uint32_t g[4], b[4], r[4];
+};
+
+template <bool LDS, int WIDE, int INTERP>
+__device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, const RgbTile<WIDE> &in_,
+                                              RgbTile<WIDE> &out, Bnd &bn)
+{
+    RgbTile<WIDE> in = in_;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { out.g[k] = 0; out.b[k] = 0; out.r[k] = 0; }
+#pragma unroll
+    for (int i = 0; i < RgbTile<WIDE>::PXT; i++) {
+        const Rgb3 o = lut_px<LDS, INTERP>(L, W, wsample<WIDE>(in.r, i), wsample<WIDE>(in.g, i), wsample<WIDE>(in.b, i), bn);
+        wput<WIDE>(out.g, i, o.g);
+        wput<WIDE>(out.b, i, o.b);
+        wput<WIDE>(out.r, i, o.r);
+        if ((i & 1) == 1) {
+            fence_words<4>(in.g); fence_words<4>(in.b); fence_words<4>(in.r);
+            fence_words<4>(out.g); fence_words<4>(out.b); fence_words<4>(out.r);
+        }
+    }
+}
+
+template <int WIDE, int INTERP>
+__global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
+void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
+{
+    using T = RgbTile<WIDE>;
+    const int lane = threadIdx.x & 63;
+    const int wib = uni(threadIdx.x >> 6);
+    const int wave = blockIdx.x * 4 + wib;
+    int t = uni(wave * TG.tiles_per_wave);
+    const int t_end = uni(min(t + TG.tiles_per_wave, TG.tiles));
+    if (t >= t_end) return;
+    const int slice_off = wib * TG.win_nodes * 16;
+    int fr = t / (TG.nsx * TG.nry);
+    int rem = t - fr * (TG.nsx * TG.nry);
+    int sx = rem / TG.nry, ry = rem - sx * TG.nry;
+    const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
+    const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
+
+    const int lds_bytes = 4 * TG.win_nodes * 16;
+    Win W, WG;
+    win_empty(W, slice_off);
+    win_global(WG, L);
+    bool lds_mode = true;
+
+    auto load_tile = [&](T &dst, int f, int tsx, int try_) {
+        const int lxc = min(lx, TG.uw - 1 - tsx * lw), lyc = min(ly, TG.urows - 1 - (try_ << lh_log2));
+        const long long row0 = G.row0 + (try_ << lh_log2);                // wave-uniform
+        const long long xb = (long long)tsx * lw * 16;
+        ldw<4>(dst.g, P.s[0] + f * P.sfs[0] + row0 * P.ss[0] + xb + (unsigned)(lyc * (int)P.ss[0] + lxc * 16));
+        ldw<4>(dst.b, P.s[1] + f * P.sfs[1] + row0 * P.ss[1] + xb + (unsigned)(lyc * (int)P.ss[1] + lxc * 16));
+        ldw<4>(dst.r, P.s[2] + f * P.sfs[2] + row0 * P.ss[2] + xb + (unsigned)(lyc * (int)P.ss[2] + lxc * 16));
+    };
+
+    T nxt;
+    load_tile(nxt, fr, sx, ry);
+    for (; t < t_end; t++) {
+        const T in = nxt;
+        const int cfr = fr, csx = sx, cry = ry;
+        if (++ry == TG.nry) {
+            ry = 0;
+            if (++sx == TG.nsx) { sx = 0; fr++; }
+        }
+        if (t + 1 < t_end) load_tile(nxt, fr, sx, ry);             // before this tile's stores (in-order vmcnt)
+
+        T out;
+        Bnd bn;
+        for (;;) {
+            bnd_reset(bn);
+            if (lds_mode) {
+                rgb_tile_body<true, WIDE, INTERP>(L, W, in, out, bn);
+                if (win_holds(W, bn)) break;
+                stat_add(TG.stats, 1, lane);
+                if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
+                else stat_add(TG.stats, 3, lane);
+            } else {
+                rgb_tile_body<false, WIDE, INTERP>(L, WG, in, out, bn);
+                stat_add(TG.stats, 2, lane);
+                if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; stat_add(TG.stats, 3, lane); }
+                break;
+            }
+        }
+        {
+            const int xu = csx * lw + lx, yu = (cry << lh_log2) + ly;
+            const bool active = xu < TG.uw && yu < TG.urows;
+            const long long row0 = G.row0 + (cry << lh_log2);
+            const long long xb = (long long)csx * lw * 16;
+            if (active) {
+                stw<4>(P.d[0] + cfr * P.dfs[0] + row0 * P.ds[0] + xb + (unsigned)(ly * (int)P.ds[0] + lx * 16), out.g);
+                stw<4>(P.d[1] + cfr * P.dfs[1] + row0 * P.ds[1] + xb + (unsigned)(ly * (int)P.ds[1] + lx * 16), out.b);
+                stw<4>(P.d[2] + cfr * P.dfs[2] + row0 * P.ds[2] + xb + (unsigned)(ly * (int)P.ds[2] + lx * 16), out.r);
+            }
+        }
+        stat_add(TG.stats, 0, lane);
+    }
+}
+
+// ================================================================= launchers
+static int g_cus = 0;
+
+static int device_cus()
+{
+    if (!g_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_cus = prop.multiProcessorCount;
+        if (g_cus <= 0) g_cus = 256;
+    }
+    return g_cus;
+}
+
+// Split the 64 lanes of a wave between x (units of one row) and y (unit rows) so that a
+// row of `uw` units wastes as few lanes as possible; prefer wide tiles (longer bursts).
+static void plan_tiles(TileGeom *tg, int uw, int urows, int nframes, int win_nodes, int waves_per_cu, unsigned *stats)
+{
+    tg->stats = stats;
+    int best = 6;
+    double best_eff = -1.0;
+    for (int l = 6; l >= 2; l--) {
+        const int lw = 1 << l, lh = 64 >> l;
+        const double eff = ((double)uw / (((uw + lw - 1) / lw) * lw)) * ((double)urows / (((urows + lh - 1) / lh) * lh));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = l; }
+    }
+    tg->lw_log2 = best;
+    tg->uw = uw;
+    tg->urows = urows;
+    tg->nsx = (uw + (1 << best) - 1) >> best;
+    tg->nry = (urows + (64 >> best) - 1) / (64 >> best);
+    tg->tiles = nframes * tg->nsx * tg->nry;
+    const int max_waves = device_cus() * waves_per_cu;
+    // at least 2 tiles per wave where the problem allows, so a staged window is reused
+    int waves = tg->tiles / 2;
+    if (waves > max_waves) waves = max_waves;
+    if (waves < 1) waves = 1;
+    tg->tiles_per_wave = (tg->tiles + waves - 1) / waves;
+    tg->win_nodes = win_nodes;
+}
+
+static int tile_blocks(const TileGeom &tg)
+{
+    const int waves = (tg.tiles + tg.tiles_per_wave - 1) / tg.tiles_per_wave;
+    return (waves + 3) / 4;
+}
+
+static int g_win_nodes = 832;       // 13 KB per wave, 52 KB per 256-thread block, 3 blocks per CU
+static int g_waves_per_cu = 12;
+static bool g_env_read = false;
+
+static void read_env_tuning()
+{
+    if (g_env_read) return;
+    g_env_read = true;
+    if (const char *e = getenv("LUTR_WIN_NODES")) { const int v = atoi(e); if (v >= 64 && v <= 2048) g_win_nodes = v; }
+    if (const char *e = getenv("LUTR_WAVES_PER_CU")) { const int v = atoi(e); if (v >= 4 && v <= 32) g_waves_per_cu = v; }
+}
+
+void tile_tuning(int win_nodes, int waves_per_cu)
+{
+    if (win_nodes >= 64) g_win_nodes = win_nodes;
+    if (waves_per_cu >= 4) g_waves_per_cu = waves_per_cu;
+}
+
+const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G, int depth, int mode,
+                            unsigned *stats)
+{
+    const int wide = depth > 8, pxt = wide ? 8 : 16;
+    TileGeom tg;
+    read_env_tuning();
+    plan_tiles(&tg, G.w / pxt, G.rows, G.nframes, g_win_nodes, g_waves_per_cu, stats);
+    const dim3 grid(tile_blocks(tg)), block(256);
+    const size_t lds = (size_t)4 * tg.win_nodes * 16;
+#define RGB_CASE(W, I) \
+    if (wide == W && mode == I) { \
+        hipLaunchKernelGGL((k_rgb_tile<W, I>), grid, block, lds, st, L, P, G, tg); \
+        return "k_rgb_tile<" #W "," #I ">"; \
+    }
+    RGB_CASE(0, 0) RGB_CASE(0, 1) RGB_CASE(0, 2)
+    RGB_CASE(1, 0) RGB_CASE(1, 1) RGB_CASE(1, 2)
+#undef RGB_CASE
+    return nullptr;
+}
+
+const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
+                            const FrameGeom &G, int win, int csx, int csy, int mode, unsigned *stats)
+{
+    const int pxt = win ? 8 : 16;
+    TileGeom tg;
+    read_env_tuning();
+    plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats);
+    const dim3 grid(tile_blocks(tg)), block(256);
+    const size_t lds = (size_t)4 * tg.win_nodes * 16;
+#define YUV_CASE(W, X, Y, I) \
+    if (win == W && csx == X && csy == Y && mode == I) { \
+        hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I>), grid, block, lds, st, L, K, P, G, tg); \
+        return "k_yuv_tile<" #W "," #X "," #Y "," #I ">"; \
+    }
+#define YUV_FMT(W, X, Y) YUV_CASE(W, X, Y, 0) YUV_CASE(W, X, Y, 1) YUV_CASE(W, X, Y, 2)
+    YUV_FMT(0, 1, 1) YUV_FMT(0, 1, 0) YUV_FMT(0, 0, 0)
+    YUV_FMT(1, 1, 1) YUV_FMT(1, 1, 0) YUV_FMT(1, 0, 0)
+#undef YUV_FMT
+#undef YUV_CASE
+    return nullptr;
+}
+
+}  // namespace lutr

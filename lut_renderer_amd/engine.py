@@ -177,6 +177,12 @@ class LutEngine:
     def last_kernel(self) -> str:
         return self._lib.lutr_ctx_last_kernel(self._ctx).decode()
 
+    def tile_stats(self, enable: bool = True) -> dict:
+        """Counters of the LDS-window kernels since the previous call; (re)arms collection."""
+        out = (C.c_uint64 * 4)()
+        _native.check(self._lib.lutr_ctx_tile_stats(self._ctx, int(enable), out))
+        return {"tiles": out[0], "misses": out[1], "global_tiles": out[2], "staged": out[3]}
+
     def sync(self) -> None:
         _native.check(self._lib.lutr_ctx_sync(self._ctx))
 

@@ -49,7 +49,7 @@ def _assert_equal(got, want, what):
                                  f"first {bad[0].tolist()} got {a[tuple(bad[0])]} want {b[tuple(bad[0])]}")
 
 
-@pytest.mark.parametrize("variant", ["generic", "vec_global"])
+@pytest.mark.parametrize("variant", ["generic", "vec_global", "vec_lds"])
 @pytest.mark.parametrize("depth", [8, 10, 12, 16])
 @pytest.mark.parametrize("lutname", ["log709_33.cube", "random_9.cube", "domain_2.cube"])
 def test_rgb_parity(engine, orc, cube_dir, variant, depth, lutname):
@@ -61,11 +61,11 @@ def test_rgb_parity(engine, orc, cube_dir, variant, depth, lutname):
             want = orc.apply_rgb(lut.table, lut.scale, depth, mode, src)
             got = _to_np(engine.apply_rgb(_to_dev(src, engine), depth=depth, interp=mode), src[0].dtype)
             _assert_equal(got, want, f"rgb {variant} d{depth} {mode} {lutname}")
-            assert variant == "generic" or "vec" in engine.last_kernel
+            assert variant == "generic" or ("vec" in engine.last_kernel or "tile" in engine.last_kernel)
     engine.set_variant("auto")
 
 
-@pytest.mark.parametrize("variant", ["generic", "vec_global"])
+@pytest.mark.parametrize("variant", ["generic", "vec_global", "vec_lds"])
 @pytest.mark.parametrize("fmt", ["yuv420p", "yuv420p10le", "yuv422p10le", "yuv444p10le", "yuv422p", "yuv444p",
                                  "yuv420p12le"])
 def test_yuv_parity(engine, orc, cube_dir, variant, fmt):
@@ -174,7 +174,7 @@ def test_full_size_properties_uhd(engine, orc, cube_dir):
     ref = engine.apply_yuv(src, pix_fmt="yuv420p10le")
     engine.set_variant("auto")
     fast = engine.apply_yuv(src, pix_fmt="yuv420p10le")
-    assert "vec" in engine.last_kernel
+    assert "tile" in engine.last_kernel
     for a, b in zip(ref, fast):
         assert torch.equal(a, b)
     # (3) idempotence of sharding: 8 row blocks == whole frame
