@@ -1,0 +1,93 @@
+"""`apply_lut`: the Python-side LUT-apply API with the reference's option vocabulary.
+
+Where the reference hands a filter string to an ffmpeg child process
+(/root/reference/src/lut_renderer/ffmpeg.py:195-247, :304-310, run at
+task_manager.py:145-151), this applies the same chain to frames already resident in HBM:
+
+    [scale=in_range=pc:out_range=R, format=<8-bit>]   full-range sources only
+    (auto) YUV -> RGB at the negotiated depth          matrix from lut_input_matrix / colorspace
+    lut3d=file=<cube>:interp=<mode>
+    [format=<pix_fmt>]                                 RGB -> YUV at the output depth
+
+Options use the names and values of `ProcessingParams` (models.py:45-56) and `VideoInfo`
+(media_info.py:25-34).  Unforced matrices fall back to BT.601, swscale's default for
+untagged frames; the RGB->YUV side produces limited range, which is
+what ffmpeg's auto-inserted scaler emits ahead of an encoder.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, Optional, Sequence, Tuple
+
+from .cube import CubeLut, read_cube
+from .params import ProcessingParams, VideoInfo, infer_bit_depth
+from .plan import LutPlan, output_color_tags, resolve_lut_plan
+
+#: FFmpeg lut3d has no "cubic"; the reference whitelists it anyway (ffmpeg.py:243) and ffmpeg
+#: would reject the filtergraph.  The engine mirrors that as an error.
+_ENGINE_INTERP = ("nearest", "trilinear", "tetrahedral", "pyramid", "prism")
+
+_lut_cache: Dict[Tuple[str, float, int], CubeLut] = {}
+
+
+def _cached_cube(path: Path) -> CubeLut:
+    st = path.stat()
+    key = (str(path), st.st_mtime, st.st_size)
+    if key not in _lut_cache:
+        _lut_cache.clear()
+        _lut_cache[key] = read_cube(path)
+    return _lut_cache[key]
+
+
+def engine_call_for(plan: LutPlan, pix_fmt: str, out_pix_fmt: Optional[str] = None) -> dict:
+    """Translate a LutPlan into keyword arguments of LutEngine.apply_yuv."""
+    from .engine import parse_pix_fmt
+    if plan.interp not in _ENGINE_INTERP:
+        raise ValueError(f"lut3d has no interpolation mode '{plan.interp}'")
+    src = parse_pix_fmt(pix_fmt)
+    if src.family != "yuv":
+        raise ValueError("apply_lut takes planar YUV frames; use LutEngine.apply_rgb for gbrp planes")
+    matrix = plan.matrix or "smpte170m"
+    kw = dict(pix_fmt=pix_fmt.replace("yuvj", "yuv"), interp=plan.interp, matrix_in=matrix, matrix_out=matrix,
+              range_out="tv")
+    if plan.prologue:
+        # scale=in_range=pc:out_range=R , format=yuv4xxp (8 bit): the LUT then runs at 8 bit
+        kw.update(range_src="pc", range_in=plan.prologue_out_range, lut_depth=8)
+        default_out = plan.intermediate_pix_fmt
+    else:
+        kw.update(range_src="tv", range_in="tv", lut_depth=src.depth)
+        default_out = kw["pix_fmt"]
+    kw["out_pix_fmt"] = out_pix_fmt or default_out
+    return kw
+
+
+def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: str, width: Optional[int] = None,
+              height: Optional[int] = None, input_matrix: str = "auto", colorspace: Optional[str] = None,
+              color_range: Optional[str] = None, output_tags: str = "bt709", out_pix_fmt: Optional[str] = None,
+              out: Optional[Sequence] = None, engine=None, devices: Sequence[int] = (0,)):
+    """Apply `cube` to planar YUV frames on the GPU.  `planes` = (Y, Cb, Cr) torch tensors on the
+    engine's device, each [H,W] or [F,H,W].  Returns (planes_out, tags) where `tags` is the colour
+    metadata the reference would write for this policy (None = inherit / none).
+
+    `engine` may be a LutEngine that already holds the lattice (then `cube` may be None);
+    otherwise one is created on devices[0] for the call."""
+    from .engine import LutEngine
+    if width is not None and planes[0].shape[-1] != width or height is not None and planes[0].shape[-2] != height:
+        raise ValueError("plane shape does not match width/height")
+    params = ProcessingParams(lut_interp=interp, lut_input_matrix=input_matrix, lut_output_tags=output_tags)
+    info = VideoInfo(width=width, height=height, pix_fmt=pix_fmt, bit_depth=infer_bit_depth(pix_fmt),
+                     colorspace=colorspace, color_range=color_range)
+    plan = resolve_lut_plan(params, cube if cube is not None else "engine.cube", info)
+    kw = engine_call_for(plan, pix_fmt, out_pix_fmt)
+    own = engine is None
+    eng = engine or LutEngine(devices[0])
+    try:
+        if cube is not None:
+            eng.set_lut(cube if isinstance(cube, CubeLut) else _cached_cube(Path(cube)))
+        result = eng.apply_yuv(planes, out, **kw)
+        if own:
+            eng.sync()
+    finally:
+        if own:
+            eng.close()
+    return result, output_color_tags(plan.output_policy)

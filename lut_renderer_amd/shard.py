@@ -24,3 +24,32 @@ def row_blocks(h: int, n: int, align: int = 2) -> List[Tuple[int, int]]:
 
 def my_rows(h: int, rank: int, world: int, align: int = 2) -> Tuple[int, int]:
     return row_blocks(h, world, align)[rank]
+
+
+def broadcast_lattice(lut, src: int = 0, group=None, device=None):
+    """The path's only collective, in its backend-neutral form: rank `src` holds a parsed
+    CubeLut, every rank returns (n, scale float32[3], table float32[n,n,n,3]).
+
+    Two broadcasts (4 floats of metadata, then 3*n^3 floats: 431,244 B for 33^3).  Over gloo it
+    runs on CPU tensors (tests); over nccl (= RCCL, xGMI) pass device=cuda:<local rank>.
+    `LutEngine.set_lut_distributed` is the zero-copy GPU variant: it broadcasts straight into
+    each rank's device lattice."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    meta = torch.zeros(4, dtype=torch.float32, device=dev)
+    if rank == src:
+        if lut is None:
+            raise ValueError("the source rank must pass the LUT")
+        meta = torch.tensor([float(lut.n), *[float(v) for v in lut.scale]], dtype=torch.float32, device=dev)
+    dist.broadcast(meta, src=src, group=group)
+    n = int(meta[0].item())
+    if rank == src:
+        table = torch.from_numpy(np.ascontiguousarray(lut.table, dtype=np.float32)).to(dev).reshape(-1)
+    else:
+        table = torch.empty(n * n * n * 3, dtype=torch.float32, device=dev)
+    dist.broadcast(table, src=src, group=group)
+    scale = meta[1:].cpu().numpy().astype(np.float32)
+    return n, scale, table.cpu().numpy().reshape(n, n, n, 3)
