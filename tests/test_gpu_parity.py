@@ -190,3 +190,53 @@ def test_full_size_properties_uhd(engine, orc, cube_dir):
     want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, strip, nthreads=8)
     got = _to_np(fast, np.uint16)
     _assert_equal([got[0][512:576], got[1][256:288], got[2][256:288]], want, "uhd strip")
+
+
+def test_apply_lut_api_follows_the_reference_options(engine, orc, cube_dir):
+    """`apply_lut` with the reference's option vocabulary (models.py:45-56) == the oracle chain the
+    same options select in the reference's filter string (SURVEY.md Appendix D cases A, E, F)."""
+    from lut_renderer_amd.api import apply_lut
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    # E: tv 10-bit bt2020nc source, input_matrix=auto -> bt2020nc both ways, 10-bit LUT, tags bt709/tv
+    src = frames.natural_yuv(128, 72, 10, 1, 1, k=12)
+    out, tags = apply_lut(_to_dev(src, engine), cube=cube_dir / "log709_33.cube", pix_fmt="yuv420p10le",
+                          colorspace="bt2020nc", color_range="tv", engine=engine)
+    k = orc.yuv_constants("bt2020nc", "tv", "bt2020nc", "tv", 10, 10, 10, 4)
+    _assert_equal(_to_np(out, np.uint16), orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src),
+                  "apply_lut case E")
+    assert tags == {"color_primaries": "bt709", "color_trc": "bt709", "colorspace": "bt709", "color_range": "tv"}
+    # F: forced bt709 matrix, trilinear
+    out, _ = apply_lut(_to_dev(src, engine), cube=None, interp="trilinear", pix_fmt="yuv420p10le",
+                       input_matrix="bt709", colorspace="bt2020nc", engine=engine)
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", 10, 10, 10, 4)
+    _assert_equal(_to_np(out, np.uint16), orc.apply_yuv(lut.table, lut.scale, "trilinear", k, 10, 10, 10, 1, 1, src),
+                  "apply_lut case F")
+    # A: yuvj420p full-range 8-bit -> prologue to tv, 8-bit LUT, yuv420p out; 'inherit' returns no tags
+    src8 = frames.uniform_yuv(128, 72, 8, 1, 1, k=13, full_range=True)
+    out, tags = apply_lut(_to_dev(src8, engine), cube=None, pix_fmt="yuvj420p", colorspace="bt709", color_range="pc",
+                          output_tags="bt709", engine=engine)
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", 8, 8, 8, 4, prologue=True)
+    _assert_equal(_to_np(out, np.uint8), orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 8, 8, 8, 1, 1, src8),
+                  "apply_lut case A")
+    _, tags = apply_lut(_to_dev(src8, engine), cube=None, pix_fmt="yuvj420p", color_range="pc",
+                        output_tags="inherit", engine=engine)
+    assert tags is None
+    with pytest.raises(ValueError):
+        apply_lut(_to_dev(src, engine), cube=None, interp="cubic", pix_fmt="yuv420p10le", engine=engine)
+
+
+def test_tile_window_statistics(engine, cube_dir):
+    """Natural content mostly hits the LDS window; uniform noise never fits and is all gather."""
+    _load(engine, cube_dir, "log709_33.cube")
+    engine.set_variant("vec_lds")
+    for dist, expect_global in (("natural", False), ("uniform", True)):
+        src = _to_dev(frames.make_yuv(dist, 1920, 1080, 10, 1, 1, k=0), engine)
+        engine.tile_stats(True)
+        engine.apply_yuv(src, pix_fmt="yuv420p10le")
+        st = engine.tile_stats(False)
+        assert st["tiles"] > 0
+        if expect_global:
+            assert st["global_tiles"] == st["tiles"]
+        else:
+            assert st["global_tiles"] + st["misses"] < 0.5 * st["tiles"]
+    engine.set_variant("auto")
