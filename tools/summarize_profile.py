@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile.sh run (gpurun_out/prof_TAG) into profiles/: a kernel-stats CSV copy,
+a counters JSON and profiles/traffic.json (HBM bytes per launch for bench.py's roofline.traffic).
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts
+128-byte requests at 64 bytes for wide coalesced streaming reads, so the read side is doubled;
+WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Both raw and corrected values are kept."""
+import csv
+import glob
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+tag, rnd = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r01"
+src = Path("gpurun_out") / f"prof_{tag}"
+dst = Path("profiles")
+dst.mkdir(exist_ok=True)
+summary = {"tag": tag}
+for f in glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")):
+    shutil.copy(f, dst / f"{rnd}_{tag}_kernel_stats.csv")
+    rows = list(csv.DictReader(open(f)))
+    summary["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage")} for r in rows[:4]]
+counters = defaultdict(list)
+kernel = None
+for sub in ("fetch", "write", "sq", "tcc"):
+    for f in glob.glob(str(src / sub / "*" / "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "lutr::k_" in r["Kernel_Name"]:
+                kernel = r["Kernel_Name"].split("(")[0]
+                counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                summary.setdefault("dispatch", {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size",
+                                                                    "Scratch_Size", "VGPR_Count", "SGPR_Count")})
+summary["kernel"] = kernel
+summary["counters_mean_per_dispatch"] = {k: sum(v) / len(v) for k, v in counters.items()}
+c = summary["counters_mean_per_dispatch"]
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    summary["hbm_bytes_per_launch"] = {
+        "fetch_raw": c["FETCH_SIZE"] * 1024, "write_raw": c["WRITE_SIZE"] * 1024,
+        "fetch_corrected_x2": 2 * c["FETCH_SIZE"] * 1024,
+        "total_corrected": 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024,
+        "note": "FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM); WRITE_SIZE exact"}
+line = (src / "bench_line.json")
+if line.exists() and line.read_text().strip():
+    b = json.loads(line.read_text())
+    summary["bench"] = {k: b[k] for k in ("value", "ms_per_step", "roofline", "config")}
+    summary["workload_tag"] = tag
+(dst / f"{rnd}_{tag}_counters.json").write_text(json.dumps(summary, indent=1) + "\n")
+if "hbm_bytes_per_launch" in summary and len(sys.argv) > 3:
+    tpath = dst / "traffic.json"
+    t = json.loads(tpath.read_text()) if tpath.exists() else {}
+    t[sys.argv[3]] = int(summary["hbm_bytes_per_launch"]["total_corrected"])
+    tpath.write_text(json.dumps(t, indent=1) + "\n")
+print(json.dumps(summary, indent=1)[:3000])
