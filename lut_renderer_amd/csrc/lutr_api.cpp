@@ -164,7 +164,7 @@ struct lutr_ctx {
     float scale[3] = {1.f, 1.f, 1.f};
     int variant = VAR_AUTO;
     std::string last_kernel;
-    unsigned *stats = nullptr;       // 4 device counters, allocated by lutr_ctx_tile_stats_enable
+    unsigned *stats = nullptr;       // 8 device counters (4 reported + clock stamps), see lutr_ctx_tile_stats
 };
 
 extern "C" {
@@ -267,20 +267,21 @@ int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[4])
     if (out) {
         for (int i = 0; i < 4; i++) out[i] = 0;
         if (c->stats) {
-            unsigned h[4];
+            unsigned h[8];
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
             for (int i = 0; i < 4; i++) out[i] = h[i];
+            if (h[5]) set_error("clock %.3f GHz (shader cycles %u / 100MHz ticks %u, >>8)", 0.1 * h[4] / h[5], h[4], h[5]);
         }
     }
     if (enable && !c->stats) {
-        HIP_TRY(hipMalloc((void **)&c->stats, 4 * sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void **)&c->stats, 8 * sizeof(unsigned)));
     } else if (!enable && c->stats) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(c->stats);
         c->stats = nullptr;
     }
-    if (c->stats) HIP_TRY(hipMemset(c->stats, 0, 4 * sizeof(unsigned)));
+    if (c->stats) HIP_TRY(hipMemset(c->stats, 0, 8 * sizeof(unsigned)));
     return LUTR_OK;
 }
 

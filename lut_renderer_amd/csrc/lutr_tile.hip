@@ -70,33 +70,33 @@ __device__ __forceinline__ void bnd_reset(Bnd &b)
     b.rmax = b.gmax = b.bmax = -1e9f;
 }
 
-// A node is read as one 16-byte access.  The empty (non-volatile, zero-instruction) asm makes
-// .x depend on .w, so hipcc cannot narrow the LDS read to ds_read_b96 just because .w is
-// padding: b96 costs 8 LDS cycles per wave-instruction, b128 costs 4 (MI355X_MICROARCH.md, LDS).
+// A node is read as one 16-byte access.  Loading through the 4-wide ext_vector type keeps it a
+// ds_read_b128 / global_load_dwordx4 even though .w is padding (a float4 struct load gets narrowed
+// to b96, which the LDS serves at 8 cycles per wave-instruction instead of 4; MI355X_MICROARCH.md).
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <bool LDS>
 __device__ __forceinline__ f4 tap(const float4 *__restrict__ lat, int a)
 {
-    if constexpr (LDS) {
-        f4 v = *(const f4 *)(lutr_smem + a);
-        float x = v.x, w = v.w;
-        asm("" : "+v"(x) : "v"(w));
-        v.x = x;
-        return v;
-    } else {
-        return *(const f4 *)((const char *)lat + a);
-    }
+    if constexpr (LDS) return *(const f4 *)(lutr_smem + a);
+    else return *(const f4 *)((const char *)lat + a);
 }
 
 struct Rgb3 { float r, g, b; };
 
 __device__ __forceinline__ float tlerp(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
 
-// One pixel of SURVEY A.3-A.5 against window W.  Integer codes in (as floats), integer
-// codes out (as floats).  Accumulates the cell bounds the window check needs.
+// One pixel of SURVEY A.3-A.5 against window W, in three stages so that a tile body can run each
+// stage for several pixels back to back (independent instructions; a lone dependent chain issues
+// one VALU per ~6 cycles on gfx950).  Integer codes in (as floats), integer codes out (as floats).
+struct PxC {
+    int a;                  // byte address of the c000 tap
+    int oa, oz;             // tetrahedral: byte offsets of the 2nd and 3rd taps
+    float w0, w1, w2, w3;   // tetrahedral weights; trilinear keeps d.r, d.g, d.b in w0..w2
+};
+
 template <bool LDS, int INTERP>
-__device__ __forceinline__ Rgb3 lut_px(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
+__device__ __forceinline__ PxC px_coords(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
 {
     const float xr = rc * L.scale_f, xg = gc * L.scale_f, xb = bc * L.scale_f;
     const float sr = tmed3(xr * L.sc[0], 0.0f, L.lut_max);
@@ -114,20 +114,46 @@ __device__ __forceinline__ Rgb3 lut_px(const LutConsts &L, const Win &W, float r
         bn.gmin = fminf(bn.gmin, hg); bn.gmax = fmaxf(bn.gmax, hg);
         bn.bmin = fminf(bn.bmin, hb); bn.bmax = fmaxf(bn.bmax, hb);
     }
-    int a;
+    PxC c;
     if constexpr (LDS) {
         // exact in fp32: every term is an integer well below 2^24 for a window of <= 4096 nodes
-        a = (int)tfma(pr, W.fr, tfma(pg, W.fg, tfma(pb, W.fb, W.fc)));
-        a = (int)min((unsigned)a, W.a_max);       // a stale window may not contain this cell: stay in LDS
+        c.a = (int)tfma(pr, W.fr, tfma(pg, W.fg, tfma(pb, W.fb, W.fc)));
+        c.a = (int)min((unsigned)c.a, W.a_max);   // a stale window may not contain this cell: stay in LDS
     } else {
-        a = (((int)pr * L.n1 + (int)pg) * L.n1 + (int)pb) * 16;
+        c.a = (((int)pr * L.n1 + (int)pg) * L.n1 + (int)pb) * 16;
     }
-    Rgb3 v;
-    if constexpr (INTERP == LUTR_INTERP_NEAREST) {
-        const f4 c = tap<LDS>(L.lat, a);
-        v.r = c.x; v.g = c.y; v.b = c.z;
-    } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
+    c.oa = c.oz = 0;
+    c.w0 = c.w1 = c.w2 = c.w3 = 0.0f;
+    if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
+        c.w0 = sr - pr; c.w1 = sg - pg; c.w2 = sb - pb;
+    } else if constexpr (INTERP == LUTR_INTERP_TETRAHEDRAL) {
+        // sorted form (see lutr_kernels.hip interp_tetrahedral for why this is bit-identical to
+        // FFmpeg's six branches on a finite lattice)
         const float dr = sr - pr, dg = sg - pg, db = sb - pb;
+        const float x = fmaxf(fmaxf(dr, dg), db), y = tmed3(dr, dg, db), z = fminf(fminf(dr, dg), db);
+        const bool rg = dr > dg, gb = dg > db, rb = dr > db;
+        // by-value copies: a ?: over struct members is an lvalue select, which pins W in scratch
+        const int o_r = W.o_r, o_g = W.o_g, o_b = W.o_b;
+        const int o111 = o_r + o_g + o_b;
+        const int z_r = o111 - o_r, z_g = o111 - o_g, z_b = o111 - o_b;
+        // first step along the axis of the largest fraction, last step along the smallest
+        c.oa = (rg && rb) ? o_r : ((!rg && gb) ? o_g : o_b);
+        c.oz = (gb && rb) ? z_b : ((!gb && rg) ? z_g : z_r);
+        c.w0 = 1.0f - x; c.w1 = x - y; c.w2 = y - z; c.w3 = z;
+    }
+    return c;
+}
+
+template <bool LDS, int INTERP>
+__device__ __forceinline__ Rgb3 px_blend(const LutConsts &L, const Win &W, const PxC &c)
+{
+    Rgb3 v;
+    const int a = c.a;
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) {
+        const f4 t = tap<LDS>(L.lat, a);
+        v.r = t.x; v.g = t.y; v.b = t.z;
+    } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
+        const float dr = c.w0, dg = c.w1, db = c.w2;
         const f4 c000 = tap<LDS>(L.lat, a), c001 = tap<LDS>(L.lat, a + W.o_b);
         const f4 c010 = tap<LDS>(L.lat, a + W.o_g), c011 = tap<LDS>(L.lat, a + W.o_g + W.o_b);
         const f4 c100 = tap<LDS>(L.lat, a + W.o_r), c101 = tap<LDS>(L.lat, a + W.o_r + W.o_b);
@@ -142,30 +168,30 @@ __device__ __forceinline__ Rgb3 lut_px(const LutConsts &L, const Win &W, float r
         TRI(x, v.r) TRI(y, v.g) TRI(z, v.b)
 #undef TRI
     } else {
-        // tetrahedral, sorted form (see lutr_kernels.hip interp_tetrahedral for why this is
-        // bit-identical to FFmpeg's six branches on a finite lattice)
-        const float dr = sr - pr, dg = sg - pg, db = sb - pb;
-        const float x = fmaxf(fmaxf(dr, dg), db), y = tmed3(dr, dg, db), z = fminf(fminf(dr, dg), db);
-        const bool rg = dr > dg, gb = dg > db, rb = dr > db;
-        // by-value copies: a ?: over struct members is an lvalue select, which pins W in scratch
-        const int o_r = W.o_r, o_g = W.o_g, o_b = W.o_b;
-        const int o111 = o_r + o_g + o_b;
-        const int z_r = o111 - o_r, z_g = o111 - o_g, z_b = o111 - o_b;
-        // first step along the axis of the largest fraction, last step along the smallest
-        const int oa = (rg && rb) ? o_r : ((!rg && gb) ? o_g : o_b);
-        const int oz = (gb && rb) ? z_b : ((!gb && rg) ? z_g : z_r);
-        const f4 c0 = tap<LDS>(L.lat, a), c1 = tap<LDS>(L.lat, a + oa);
-        const f4 c2 = tap<LDS>(L.lat, a + oz), c3 = tap<LDS>(L.lat, a + o111);
-        const float w0 = 1.0f - x, w1 = x - y, w2 = y - z, w3 = z;
-        v.r = w0 * c0.x + w1 * c1.x + w2 * c2.x + w3 * c3.x;
-        v.g = w0 * c0.y + w1 * c1.y + w2 * c2.y + w3 * c3.y;
-        v.b = w0 * c0.z + w1 * c1.z + w2 * c2.z + w3 * c3.z;
+        const int o111 = W.o_r + W.o_g + W.o_b;
+        const f4 c0 = tap<LDS>(L.lat, a), c1 = tap<LDS>(L.lat, a + c.oa);
+        const f4 c2 = tap<LDS>(L.lat, a + c.oz), c3 = tap<LDS>(L.lat, a + o111);
+        v.r = c.w0 * c0.x + c.w1 * c1.x + c.w2 * c2.x + c.w3 * c3.x;
+        v.g = c.w0 * c0.y + c.w1 * c1.y + c.w2 * c2.y + c.w3 * c3.y;
+        v.b = c.w0 * c0.z + c.w1 * c1.z + c.w2 * c2.z + c.w3 * c3.z;
     }
+    return v;
+}
+
+__device__ __forceinline__ Rgb3 px_quant(const LutConsts &L, const Rgb3 &v)
+{
     Rgb3 o;
     o.r = tmed3(truncf(v.r * L.maxf), 0.0f, L.maxf);
     o.g = tmed3(truncf(v.g * L.maxf), 0.0f, L.maxf);
     o.b = tmed3(truncf(v.b * L.maxf), 0.0f, L.maxf);
     return o;
+}
+
+template <bool LDS, int INTERP>
+__device__ __forceinline__ Rgb3 lut_px(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
+{
+    const PxC c = px_coords<LDS, INTERP>(L, W, rc, gc, bc, bn);
+    return px_quant(L, px_blend<LDS, INTERP>(L, W, c));
 }
 
 // ---------------------------------------------------------------- window management
@@ -203,9 +229,14 @@ __device__ __forceinline__ bool win_holds(const Win &W, const Bnd &b)
 // misses), stage it into this wave's LDS slice and describe it in W.  The r axis takes the
 // rest of the capacity, centred.  Returns false (W untouched) when the tile's colours are too
 // spread out for the slice.
-__device__ __forceinline__ bool win_restage(Win &W, const LutConsts &L, const Bnd &bn, int cap, int slice_off,
+__device__ __forceinline__ bool win_restage(Win &W, const LutConsts &L, const Bnd &bn_, int cap, int slice_off,
                                             int lds_bytes, int lane)
 {
+    // The reductions below are 36 dependent ds_bpermute round trips.  They are side-effect free, so
+    // hipcc hoists them out of the (rare) miss branch into every tile unless their inputs pass
+    // through a volatile asm that can only execute inside the branch.
+    Bnd bn = bn_;
+    asm volatile("" : "+v"(bn.rmin), "+v"(bn.rmax), "+v"(bn.gmin), "+v"(bn.gmax), "+v"(bn.bmin), "+v"(bn.bmax));
     const int rmin = uni((int)wave_min(bn.rmin)), rmax = uni((int)wave_max(bn.rmax));
     const int gmin = uni((int)wave_min(bn.gmin)), gmax = uni((int)wave_max(bn.gmax));
     const int bmin = uni((int)wave_min(bn.bmin)), bmax = uni((int)wave_max(bn.bmax));
@@ -246,10 +277,17 @@ __device__ __forceinline__ bool win_restage(Win &W, const LutConsts &L, const Bn
 
 // optional per-launch statistics (tests, tuning): [0] tiles, [1] LDS passes that missed,
 // [2] tiles computed by the global-gather body, [3] windows staged
-__device__ __forceinline__ void stat_add(unsigned *stats, int which, int lane)
-{
-    if (stats && lane == 0) atomicAdd(&stats[which], 1u);
-}
+struct WaveStats {
+    unsigned n[4];
+    __device__ __forceinline__ WaveStats() : n{0, 0, 0, 0} {}
+    __device__ __forceinline__ void flush(unsigned *stats, int lane) const
+    {
+        if (stats && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) atomicAdd(&stats[i], n[i]);
+        }
+    }
+};
 
 // ---------------------------------------------------------------- sample helpers
 template <int WIDE>
@@ -271,14 +309,16 @@ template <int NW>
 __device__ __forceinline__ void ldw(uint32_t *w, const uint8_t *p)
 {
     if constexpr (NW == 4) { const uint4 v = *(const uint4 *)p; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-    else { const uint2 v = *(const uint2 *)p; w[0] = v.x; w[1] = v.y; }
+    else if constexpr (NW == 2) { const uint2 v = *(const uint2 *)p; w[0] = v.x; w[1] = v.y; }
+    else w[0] = *(const uint32_t *)p;
 }
 
 template <int NW>
 __device__ __forceinline__ void stw(uint8_t *p, const uint32_t *w)
 {
     if constexpr (NW == 4) *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]);
-    else *(uint2 *)p = make_uint2(w[0], w[1]);
+    else if constexpr (NW == 2) *(uint2 *)p = make_uint2(w[0], w[1]);
+    else *(uint32_t *)p = w[0];
 }
 
 // Zero-instruction ordering fence.  hipcc's instruction selection linearises an unrolled block
@@ -303,77 +343,108 @@ struct TileGeom {
     int uw, urows;        // units per row, unit rows (a unit = PXT px x BH rows)
     int nsx, nry;         // tiles across, tiles down
     int tiles;            // nframes * nsx * nry
+    int seg, nrs;         // a wave owns `seg` consecutive tile rows of one strip; nrs = segments down a frame
+    int waves;            // nframes * nrs * nsx; wave id = (frame * nrs + segment) * nsx + strip, so the
+                          // waves running side by side cover the SAME rows (shared DRAM pages / TLB entries)
     int tiles_per_wave;
     int win_nodes;        // LDS window capacity per wave, in 16-byte nodes
     unsigned *stats;      // optional device counters (see stat_add); nullptr = off
 };
 
 // ================================================================= fused YUV tile kernel
+// A unit is what one lane handles per tile: PXT luma samples wide, BH rows tall.  With
+// LUTR_UNIT_HALF the unit is 8 bytes of luma per row instead of 16: half the input / output /
+// prefetch registers per lane (more waves per SIMD) at twice the per-tile overhead per pixel.
+#ifndef LUTR_UNIT_HALF
+#define LUTR_UNIT_HALF 0
+#endif
 template <int WIDE, int CSX, int CSY>
 struct YuvTile {
-    static constexpr int PXT = WIDE ? 8 : 16;
+    static constexpr int PXT = (WIDE ? 8 : 16) >> LUTR_UNIT_HALF;
     static constexpr int BH = 1 << CSY, BW = 1 << CSX;
     static constexpr int NC = PXT >> CSX;
-    static constexpr int CW = NC * (WIDE ? 2 : 1) / 4;
-    uint32_t y[BH][4], cb[CW], cr[CW];
+    static constexpr int YW = 4 >> LUTR_UNIT_HALF;                 // 32-bit words of luma per row
+    static constexpr int CW = NC * (WIDE ? 2 : 1) / 4;             // 32-bit words of each chroma plane
+    uint32_t y[BH][YW], cb[CW], cr[CW];
 };
 
-template <bool LDS, int WIDE, int CSX, int CSY, int INTERP>
+template <bool LDS, int WIDE, int CSX, int CSY, int INTERP, bool PRE>
 __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConsts &K, const Win &W,
-                                              const YuvTile<WIDE, CSX, CSY> &in_, YuvTile<WIDE, CSX, CSY> &out, Bnd &bn)
+                                              YuvTile<WIDE, CSX, CSY> &in, YuvTile<WIDE, CSX, CSY> &out, Bnd &bn)
 {
+    // `in` is consumed: the ordering fences below run its words through volatile asm, so the caller
+    // must re-load the tile before a second pass (only after a window miss)
     using T = YuvTile<WIDE, CSX, CSY>;
-    T in = in_;
+    // a group = 4 pixels: all BH rows of GW columns; it owns NCG chroma samples
+    constexpr int GW = 4 / T::BH, NG = T::PXT / GW, NCG = (GW >> CSX) > 0 ? (GW >> CSX) : 1;
 #pragma unroll
     for (int dy = 0; dy < T::BH; dy++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) out.y[dy][k] = 0;
+        for (int k = 0; k < T::YW; k++) out.y[dy][k] = 0;
 #pragma unroll
     for (int k = 0; k < T::CW; k++) { out.cb[k] = 0; out.cr[k] = 0; }
-    const bool pre = K.pre != 0.0f;
 #pragma unroll
-    for (int j = 0; j < T::NC; j++) {
-        float cbv = wsample<WIDE>(in.cb, j), crv = wsample<WIDE>(in.cr, j);
-        if (pre) {
-            cbv = cfloor(tfma(K.pc, cbv, K.pcb), K.pre_max);
-            crv = cfloor(tfma(K.pc, crv, K.pcb), K.pre_max);
-        }
-        const float cbd = cbv - K.coff, crd = crv - K.coff;
-        const float rv = K.krv * crd, gv = tfma(K.kgu, cbd, K.kgv * crd), bu = K.kbu * cbd;
-        float rs = 0.f, gs = 0.f, bs = 0.f;
+    for (int g = 0; g < NG; g++) {
+        // ---- stage A: chroma terms, integer RGB, lattice coordinates, weights (4 independent pixels)
+        float rv[NCG], gv[NCG], bu[NCG];
 #pragma unroll
-        for (int dy = 0; dy < T::BH; dy++) {
-#pragma unroll
-            for (int dx = 0; dx < T::BW; dx++) {
-                const int i = j * T::BW + dx;
-                float yv = wsample<WIDE>(in.y[dy], i);
-                if (pre) yv = cfloor(tfma(K.py, yv, K.pyb), K.pre_max);
-                const float yy = tfma(K.ky, yv, K.yb);
-                const float rq = cfloor(yy + rv, K.max_l), gq = cfloor(yy + gv, K.max_l), bq = cfloor(yy + bu, K.max_l);
-                const Rgb3 o = lut_px<LDS, INTERP>(L, W, rq, gq, bq, bn);
-                rs += o.r; gs += o.g; bs += o.b;
-                wput<WIDE>(out.y[dy], i, cfloor(tfma(K.cyr, o.r, tfma(K.cyg, o.g, tfma(K.cyb, o.b, K.yob))), K.max_o));
+        for (int c = 0; c < NCG; c++) {
+            const int j = g * NCG + c;
+            float cbv = wsample<WIDE>(in.cb, j), crv = wsample<WIDE>(in.cr, j);
+            if constexpr (PRE) {
+                cbv = cfloor(tfma(K.pc, cbv, K.pcb), K.pre_max);
+                crv = cfloor(tfma(K.pc, crv, K.pcb), K.pre_max);
             }
+            const float cbd = cbv - K.coff, crd = crv - K.coff;
+            rv[c] = K.krv * crd; gv[c] = tfma(K.kgu, cbd, K.kgv * crd); bu[c] = K.kbu * cbd;
         }
-        wput<WIDE>(out.cb, j, cfloor(tfma(K.cbr, rs, tfma(K.cbg, gs, tfma(K.cbb, bs, K.cob))), K.max_o));
-        wput<WIDE>(out.cr, j, cfloor(tfma(K.crr, rs, tfma(K.crg, gs, tfma(K.crb, bs, K.cob))), K.max_o));
+        PxC pc[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
+            float yv = wsample<WIDE>(in.y[dy], i);
+            if constexpr (PRE) yv = cfloor(tfma(K.py, yv, K.pyb), K.pre_max);
+            const float yy = tfma(K.ky, yv, K.yb);
+            const float rq = cfloor(yy + rv[c], K.max_l), gq = cfloor(yy + gv[c], K.max_l), bq = cfloor(yy + bu[c], K.max_l);
+            pc[p] = px_coords<LDS, INTERP>(L, W, rq, gq, bq, bn);
+        }
+        // ---- stage B: taps and blend (pairs keep 8 reads in flight), stage C: outputs
+        Rgb3 o[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = px_quant(L, px_blend<LDS, INTERP>(L, W, pc[p]));
+        float rs[NCG], gs[NCG], bs[NCG];
+#pragma unroll
+        for (int c = 0; c < NCG; c++) { rs[c] = 0.f; gs[c] = 0.f; bs[c] = 0.f; }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
+            rs[c] += o[p].r; gs[c] += o[p].g; bs[c] += o[p].b;
+            wput<WIDE>(out.y[dy], i, cfloor(tfma(K.cyr, o[p].r, tfma(K.cyg, o[p].g, tfma(K.cyb, o[p].b, K.yob))), K.max_o));
+        }
+#pragma unroll
+        for (int c = 0; c < NCG; c++) {
+            const int j = g * NCG + c;
+            wput<WIDE>(out.cb, j, cfloor(tfma(K.cbr, rs[c], tfma(K.cbg, gs[c], tfma(K.cbb, bs[c], K.cob))), K.max_o));
+            wput<WIDE>(out.cr, j, cfloor(tfma(K.crr, rs[c], tfma(K.crg, gs[c], tfma(K.crb, bs[c], K.cob))), K.max_o));
+        }
         // emit the unit group by group (see fence_words)
-        fence_words<4 * T::BH>(&in.y[0][0]);
+        fence_words<T::YW * T::BH>(&in.y[0][0]);
         fence_words<T::CW>(in.cb);
         fence_words<T::CW>(in.cr);
-        fence_words<4 * T::BH>(&out.y[0][0]);
+        fence_words<T::YW * T::BH>(&out.y[0][0]);
         fence_words<T::CW>(out.cb);
         fence_words<T::CW>(out.cr);
     }
 }
 
-// 3 waves per SIMD: the unit's live set is ~160 VGPRs; capping at 128 (4 waves) spills into the
-// hot loop and is slower (measured: 214-245 vs 249-253 Gpx/s on UHD yuv420p10le tetrahedral).
+// 4 waves per SIMD: the kernel needs 127 VGPRs once the input tile is consumed in place (keeping
+// a pristine copy for the rare miss pass cost 41 registers).  5 waves (96 VGPRs) spills into
+// the hot loop and is slower (232 vs 284 Gpx/s on UHD yuv420p10le tetrahedral).
 #ifndef LUTR_TILE_WAVES_PER_EU
-#define LUTR_TILE_WAVES_PER_EU 3
+#define LUTR_TILE_WAVES_PER_EU 4
 #endif
 
-template <int WIDE, int CSX, int CSY, int INTERP>
+template <int WIDE, int CSX, int CSY, int INTERP, bool PRE>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
 void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
 {
@@ -381,15 +452,15 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int wave = blockIdx.x * 4 + wib;
-    int t = uni(wave * TG.tiles_per_wave);
-    const int t_end = uni(min(t + TG.tiles_per_wave, TG.tiles));
-    if (t >= t_end) return;                                   // wave-uniform; no barrier is ever used
+    if (wave >= TG.waves) return;                             // wave-uniform; no barrier is ever used
     const int slice_off = wib * TG.win_nodes * 16;
-
-    // tile id -> (frame, strip, tile row); consecutive ids walk DOWN a strip
-    int fr = t / (TG.nsx * TG.nry);
-    int rem = t - fr * (TG.nsx * TG.nry);
-    int sx = rem / TG.nry, ry = rem - sx * TG.nry;
+    // wave id -> (frame, row segment, strip); the wave walks DOWN its strip inside the segment
+    int fr = wave / (TG.nrs * TG.nsx);
+    const int rem = wave - fr * (TG.nrs * TG.nsx);
+    const int seg_i = rem / TG.nsx;
+    int sx = rem - seg_i * TG.nsx, ry = seg_i * TG.seg;
+    int t = 0;
+    const int t_end = uni(min(TG.seg, TG.nry - ry));
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
@@ -399,33 +470,32 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
     win_empty(W, slice_off);
     win_global(WG, L);
     bool lds_mode = true;                                     // optimistic; the first tile misses and stages
-    constexpr int CWB = T::CW * 4;
+    constexpr int CWB = T::CW * 4, YWB = T::YW * 4;
 
     // Input words of a tile.  Idle lanes of edge tiles re-read a valid unit of the same tile.
     auto load_tile = [&](T &dst, int f, int tsx, int try_) {
         const int lxc = min(lx, TG.uw - 1 - tsx * lw), lyc = min(ly, TG.urows - 1 - (try_ << lh_log2));
         const long long urow0 = cr0 + (try_ << lh_log2);                  // wave-uniform
-        const uint8_t *sy = P.s[0] + f * P.sfs[0] + urow0 * T::BH * P.ss[0] + (long long)tsx * lw * 16;
+        const uint8_t *sy = P.s[0] + f * P.sfs[0] + urow0 * T::BH * P.ss[0] + (long long)tsx * lw * YWB;
         const uint8_t *scb = P.s[1] + f * P.sfs[1] + urow0 * P.ss[1] + (long long)tsx * lw * CWB;
         const uint8_t *scr = P.s[2] + f * P.sfs[2] + urow0 * P.ss[2] + (long long)tsx * lw * CWB;
 #pragma unroll
         for (int dy = 0; dy < T::BH; dy++)
-            ldw<4>(dst.y[dy], sy + (unsigned)((lyc * T::BH + dy) * (int)P.ss[0] + lxc * 16));
+            ldw<T::YW>(dst.y[dy], sy + (unsigned)((lyc * T::BH + dy) * (int)P.ss[0] + lxc * YWB));
         ldw<T::CW>(dst.cb, scb + (unsigned)(lyc * (int)P.ss[1] + lxc * CWB));
         ldw<T::CW>(dst.cr, scr + (unsigned)(lyc * (int)P.ss[2] + lxc * CWB));
     };
 
+    WaveStats ws;
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     T nxt;
     load_tile(nxt, fr, sx, ry);
     for (; t < t_end; t++) {
-        const T in = nxt;
+        T in = nxt;
         const int cfr = fr, csx = sx, cry = ry;
         // advance to the next tile and issue its loads NOW: vmcnt retires in order, so loads issued
         // after this tile's stores would wait for those stores to be acknowledged by HBM
-        if (++ry == TG.nry) {
-            ry = 0;
-            if (++sx == TG.nsx) { sx = 0; fr++; }
-        }
+        ry++;
         if (t + 1 < t_end) load_tile(nxt, fr, sx, ry);
 
         T out;
@@ -433,17 +503,18 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
         for (;;) {
             bnd_reset(bn);
             if (lds_mode) {
-                yuv_tile_body<true, WIDE, CSX, CSY, INTERP>(L, K, W, in, out, bn);
+                yuv_tile_body<true, WIDE, CSX, CSY, INTERP, PRE>(L, K, W, in, out, bn);
                 if (win_holds(W, bn)) break;
                 // miss: re-stage around this tile's colours and redo it, or give the tile to the gather body
-                stat_add(TG.stats, 1, lane);
+                ws.n[1]++;
                 if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
-                else stat_add(TG.stats, 3, lane);
+                else ws.n[3]++;
+                load_tile(in, cfr, csx, cry);          // the failed pass consumed the tile; L2 still has it
             } else {
-                yuv_tile_body<false, WIDE, CSX, CSY, INTERP>(L, K, WG, in, out, bn);
-                stat_add(TG.stats, 2, lane);
+                yuv_tile_body<false, WIDE, CSX, CSY, INTERP, PRE>(L, K, WG, in, out, bn);
+                ws.n[2]++;
                 // colours narrow enough again?  then the next tile starts from a staged window
-                if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; stat_add(TG.stats, 3, lane); }
+                if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
                 break;
             }
         }
@@ -451,18 +522,23 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
             const int xu = csx * lw + lx, yu = (cry << lh_log2) + ly;
             const bool active = xu < TG.uw && yu < TG.urows;
             const long long urow0 = cr0 + (cry << lh_log2);
-            uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * P.ds[0] + (long long)csx * lw * 16;
+            uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * P.ds[0] + (long long)csx * lw * YWB;
             uint8_t *dcb = P.d[1] + cfr * P.dfs[1] + urow0 * P.ds[1] + (long long)csx * lw * CWB;
             uint8_t *dcr = P.d[2] + cfr * P.dfs[2] + urow0 * P.ds[2] + (long long)csx * lw * CWB;
             if (active) {
 #pragma unroll
                 for (int dy = 0; dy < T::BH; dy++)
-                    stw<4>(dy_ + (unsigned)((ly * T::BH + dy) * (int)P.ds[0] + lx * 16), out.y[dy]);
+                    stw<T::YW>(dy_ + (unsigned)((ly * T::BH + dy) * (int)P.ds[0] + lx * YWB), out.y[dy]);
                 stw<T::CW>(dcb + (unsigned)(ly * (int)P.ds[1] + lx * CWB), out.cb);
                 stw<T::CW>(dcr + (unsigned)(ly * (int)P.ds[2] + lx * CWB), out.cr);
             }
         }
-        stat_add(TG.stats, 0, lane);
+        ws.n[0]++;
+    }
+    ws.flush(TG.stats, lane);
+    if (TG.stats && lane == 0 && (wave & 255) == 0) {      // a few waves report their clock: cycles / 100 MHz ticks
+        atomicAdd(&TG.stats[4], (unsigned)((__builtin_amdgcn_s_memtime() - clk0) >> 8));
+        atomicAdd(&TG.stats[5], (unsigned)((__builtin_amdgcn_s_memrealtime() - rt0) >> 8));
     }
 }
 
@@ -474,10 +550,9 @@ struct RgbTile {
 };
 
 template <bool LDS, int WIDE, int INTERP>
-__device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, const RgbTile<WIDE> &in_,
+__device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, RgbTile<WIDE> &in,
                                               RgbTile<WIDE> &out, Bnd &bn)
 {
-    RgbTile<WIDE> in = in_;
 #pragma unroll
     for (int k = 0; k < 4; k++) { out.g[k] = 0; out.b[k] = 0; out.r[k] = 0; }
 #pragma unroll
@@ -501,13 +576,15 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int wave = blockIdx.x * 4 + wib;
-    int t = uni(wave * TG.tiles_per_wave);
-    const int t_end = uni(min(t + TG.tiles_per_wave, TG.tiles));
-    if (t >= t_end) return;
+    if (wave >= TG.waves) return;                             // wave-uniform; no barrier is ever used
     const int slice_off = wib * TG.win_nodes * 16;
-    int fr = t / (TG.nsx * TG.nry);
-    int rem = t - fr * (TG.nsx * TG.nry);
-    int sx = rem / TG.nry, ry = rem - sx * TG.nry;
+    // wave id -> (frame, row segment, strip); the wave walks DOWN its strip inside the segment
+    int fr = wave / (TG.nrs * TG.nsx);
+    const int rem = wave - fr * (TG.nrs * TG.nsx);
+    const int seg_i = rem / TG.nsx;
+    int sx = rem - seg_i * TG.nsx, ry = seg_i * TG.seg;
+    int t = 0;
+    const int t_end = uni(min(TG.seg, TG.nry - ry));
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
 
@@ -526,15 +603,13 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
         ldw<4>(dst.r, P.s[2] + f * P.sfs[2] + row0 * P.ss[2] + xb + (unsigned)(lyc * (int)P.ss[2] + lxc * 16));
     };
 
+    WaveStats ws;
     T nxt;
     load_tile(nxt, fr, sx, ry);
     for (; t < t_end; t++) {
-        const T in = nxt;
+        T in = nxt;
         const int cfr = fr, csx = sx, cry = ry;
-        if (++ry == TG.nry) {
-            ry = 0;
-            if (++sx == TG.nsx) { sx = 0; fr++; }
-        }
+        ry++;
         if (t + 1 < t_end) load_tile(nxt, fr, sx, ry);             // before this tile's stores (in-order vmcnt)
 
         T out;
@@ -544,13 +619,14 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
             if (lds_mode) {
                 rgb_tile_body<true, WIDE, INTERP>(L, W, in, out, bn);
                 if (win_holds(W, bn)) break;
-                stat_add(TG.stats, 1, lane);
+                ws.n[1]++;
                 if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
-                else stat_add(TG.stats, 3, lane);
+                else ws.n[3]++;
+                load_tile(in, cfr, csx, cry);
             } else {
                 rgb_tile_body<false, WIDE, INTERP>(L, WG, in, out, bn);
-                stat_add(TG.stats, 2, lane);
-                if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; stat_add(TG.stats, 3, lane); }
+                ws.n[2]++;
+                if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
                 break;
             }
         }
@@ -565,8 +641,9 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
                 stw<4>(P.d[2] + cfr * P.dfs[2] + row0 * P.ds[2] + xb + (unsigned)(ly * (int)P.ds[2] + lx * 16), out.r);
             }
         }
-        stat_add(TG.stats, 0, lane);
+        ws.n[0]++;
     }
+    ws.flush(TG.stats, lane);
 }
 
 // ================================================================= launchers
@@ -603,22 +680,24 @@ static void plan_tiles(TileGeom *tg, int uw, int urows, int nframes, int win_nod
     tg->nry = (urows + (64 >> best) - 1) / (64 >> best);
     tg->tiles = nframes * tg->nsx * tg->nry;
     const int max_waves = device_cus() * waves_per_cu;
-    // at least 2 tiles per wave where the problem allows, so a staged window is reused
-    int waves = tg->tiles / 2;
-    if (waves > max_waves) waves = max_waves;
-    if (waves < 1) waves = 1;
-    tg->tiles_per_wave = (tg->tiles + waves - 1) / waves;
+    // row segments: enough waves to fill the chip once when the job allows, at least 2 tiles per wave
+    // so a staged window is reused
+    long long strips = (long long)nframes * tg->nsx;
+    int nrs = (int)(max_waves / strips);                     // floor: never more waves than fit at once
+    if (nrs < 1) nrs = 1;
+    if (nrs > (tg->nry + 3) / 4) nrs = (tg->nry + 3) / 4;    // >= 4 tiles per wave: a staged window gets reused
+    if (nrs < 1) nrs = 1;
+    tg->seg = (tg->nry + nrs - 1) / nrs;
+    tg->nrs = (tg->nry + tg->seg - 1) / tg->seg;
+    tg->waves = nframes * tg->nrs * tg->nsx;
+    tg->tiles_per_wave = tg->seg;
     tg->win_nodes = win_nodes;
 }
 
-static int tile_blocks(const TileGeom &tg)
-{
-    const int waves = (tg.tiles + tg.tiles_per_wave - 1) / tg.tiles_per_wave;
-    return (waves + 3) / 4;
-}
+static int tile_blocks(const TileGeom &tg) { return (tg.waves + 3) / 4; }
 
-static int g_win_nodes = 832;       // 13 KB per wave, 52 KB per 256-thread block, 3 blocks per CU
-static int g_waves_per_cu = 12;
+static int g_win_nodes = 640;       // 10 KB per wave, 40 KB per 256-thread block, 4 blocks per CU = all 160 KB
+static int g_waves_per_cu = 16;
 static bool g_env_read = false;
 
 static void read_env_tuning()
@@ -658,16 +737,18 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
 const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
                             const FrameGeom &G, int win, int csx, int csy, int mode, unsigned *stats)
 {
-    const int pxt = win ? 8 : 16;
+    const int pxt = (win ? 8 : 16) >> LUTR_UNIT_HALF;
     TileGeom tg;
     read_env_tuning();
     plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats);
     const dim3 grid(tile_blocks(tg)), block(256);
     const size_t lds = (size_t)4 * tg.win_nodes * 16;
+    const bool pre = K.pre != 0.0f;
 #define YUV_CASE(W, X, Y, I) \
     if (win == W && csx == X && csy == Y && mode == I) { \
-        hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I>), grid, block, lds, st, L, K, P, G, tg); \
-        return "k_yuv_tile<" #W "," #X "," #Y "," #I ">"; \
+        if (pre) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true>), grid, block, lds, st, L, K, P, G, tg); \
+        else hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false>), grid, block, lds, st, L, K, P, G, tg); \
+        return pre ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"; \
     }
 #define YUV_FMT(W, X, Y) YUV_CASE(W, X, Y, 0) YUV_CASE(W, X, Y, 1) YUV_CASE(W, X, Y, 2)
     YUV_FMT(0, 1, 1) YUV_FMT(0, 1, 0) YUV_FMT(0, 0, 0)

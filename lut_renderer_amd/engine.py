@@ -181,7 +181,11 @@ class LutEngine:
         """Counters of the LDS-window kernels since the previous call; (re)arms collection."""
         out = (C.c_uint64 * 4)()
         _native.check(self._lib.lutr_ctx_tile_stats(self._ctx, int(enable), out))
-        return {"tiles": out[0], "misses": out[1], "global_tiles": out[2], "staged": out[3]}
+        res = {"tiles": out[0], "misses": out[1], "global_tiles": out[2], "staged": out[3]}
+        msg = self._lib.lutr_last_error().decode()
+        if msg.startswith("clock "):
+            res["clock"] = msg
+        return res
 
     def sync(self) -> None:
         _native.check(self._lib.lutr_ctx_sync(self._ctx))

@@ -230,7 +230,8 @@ def test_tile_window_statistics(engine, cube_dir):
     _load(engine, cube_dir, "log709_33.cube")
     engine.set_variant("vec_lds")
     for dist, expect_global in (("natural", False), ("uniform", True)):
-        src = _to_dev(frames.make_yuv(dist, 1920, 1080, 10, 1, 1, k=0), engine)
+        one = _to_dev(frames.make_yuv(dist, 1920, 1080, 10, 1, 1, k=0), engine)
+        src = [t.unsqueeze(0).repeat(16, 1, 1) for t in one]      # a batch: waves get long strips to walk
         engine.tile_stats(True)
         engine.apply_yuv(src, pix_fmt="yuv420p10le")
         st = engine.tile_stats(False)
