@@ -164,6 +164,7 @@ struct lutr_ctx {
     float scale[3] = {1.f, 1.f, 1.f};
     int variant = VAR_AUTO;
     std::string last_kernel;
+    unsigned *queue = nullptr;       // work-queue counter of the tile kernels (device), zeroed per launch
     unsigned *stats = nullptr;       // 8 device counters (4 reported + clock stamps), see lutr_ctx_tile_stats
 };
 
@@ -219,6 +220,12 @@ int lutr_ctx_create(int device, lutr_ctx **out)
         return hip_fail(e, "hipStreamCreateWithFlags");
     }
     c->stream = c->own_stream;
+    e = hipMalloc((void **)&c->queue, sizeof(unsigned));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return hip_fail(e, "hipMalloc(queue)");
+    }
     *out = c;
     return LUTR_OK;
 }
@@ -229,6 +236,7 @@ void lutr_ctx_destroy(lutr_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->lat) (void)hipFree(c->lat);
     if (c->stats) (void)hipFree(c->stats);
+    if (c->queue) (void)hipFree(c->queue);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -267,21 +275,22 @@ int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[4])
     if (out) {
         for (int i = 0; i < 4; i++) out[i] = 0;
         if (c->stats) {
-            unsigned h[8];
+            unsigned h[12];
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
             for (int i = 0; i < 4; i++) out[i] = h[i];
-            if (h[5]) set_error("clock %.3f GHz (shader cycles %u / 100MHz ticks %u, >>8)", 0.1 * h[4] / h[5], h[4], h[5]);
+            if (h[5]) set_error("clock %.3f GHz (shader cycles %u / 100MHz ticks %u, >>8) segs issue-prefetch %u wait-input %u body %u stores %u; wave life max %.1f us, sum/64 %u ticks",
+                                0.1 * h[4] / h[5], h[4], h[5], h[6], h[7], h[8], h[9], h[10] / 100.0, h[11]);
         }
     }
     if (enable && !c->stats) {
-        HIP_TRY(hipMalloc((void **)&c->stats, 8 * sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void **)&c->stats, 12 * sizeof(unsigned)));
     } else if (!enable && c->stats) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(c->stats);
         c->stats = nullptr;
     }
-    if (c->stats) HIP_TRY(hipMemset(c->stats, 0, 8 * sizeof(unsigned)));
+    if (c->stats) HIP_TRY(hipMemset(c->stats, 0, 12 * sizeof(unsigned)));
     return LUTR_OK;
 }
 
@@ -417,7 +426,7 @@ int lutr_apply_planar_rgb(lutr_ctx *c, int depth, int interp, int w, int h, int 
     LutConsts L; PlaneSet P; FrameGeom G{w, h, row0, rows, nframes};
     fill_lut(&L, c, depth);
     fill_planes(&P, src, dst);
-    return finish_launch(c, launch_rgb(c->stream, c->variant, L, P, G, depth, interp, c->stats));
+    return finish_launch(c, launch_rgb(c->stream, c->variant, L, P, G, depth, interp, c->stats, c->queue));
 }
 
 int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int h, int nframes,
@@ -443,7 +452,7 @@ int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int
     fill_lut(&L, c, p->lut_depth);
     fill_planes(&P, src, dst);
     return finish_launch(c, launch_yuv(c->stream, c->variant, L, K, P, G, LUTR_FMT_DEPTH(p->fmt_in),
-                                       LUTR_FMT_DEPTH(p->fmt_out), csx, csy, interp, c->stats));
+                                       LUTR_FMT_DEPTH(p->fmt_out), csx, csy, interp, c->stats, c->queue));
 }
 
 }  // extern "C"

@@ -52,16 +52,16 @@ enum Variant { VAR_AUTO = 0, VAR_GENERIC = 1, VAR_VEC_GLOBAL = 2, VAR_VEC_LDS = 
 // launchers (lutr_kernels.hip); return the kernel's name, or nullptr when the variant
 // cannot take this layout (caller then falls back to the generic kernel)
 const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const PlaneSet &P,
-                       const FrameGeom &G, int depth, int interp, unsigned *stats);
+                       const FrameGeom &G, int depth, int interp, unsigned *stats, unsigned *queue);
 const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const YuvConsts &K,
                        const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy,
-                       int interp, unsigned *stats);
+                       int interp, unsigned *stats, unsigned *queue);
 
 // persistent LDS-window kernels (lutr_tile.hip); layout already checked by launch_rgb/launch_yuv
 const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G,
-                            int depth, int interp, unsigned *stats);
+                            int depth, int interp, unsigned *stats, unsigned *queue);
 const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
-                            const FrameGeom &G, int wide, int csx, int csy, int interp, unsigned *stats);
+                            const FrameGeom &G, int wide, int csx, int csy, int interp, unsigned *stats, unsigned *queue);
 
 // host helpers (yuv_consts.cpp / cube_parse.cpp)
 int make_yuv_consts(const lutr_yuv_params &p, YuvConsts *out);

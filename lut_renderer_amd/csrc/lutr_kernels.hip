@@ -458,7 +458,7 @@ static unsigned grid_for(long long units, unsigned cap = 0x7fffffffu)
 }
 
 const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const PlaneSet &P,
-                       const FrameGeom &G, int depth, int mode, unsigned *stats)
+                       const FrameGeom &G, int depth, int mode, unsigned *stats, unsigned *queue)
 {
     const int wide = depth > 8;
     const int pxt = wide ? 8 : 16;
@@ -469,7 +469,7 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
         vec_ok = planes_aligned(P, c, 16, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
     if (vec_ok && (variant == VAR_AUTO || variant == VAR_VEC_LDS))
-        return launch_rgb_tile(st, L, P, G, depth, mode, stats);
+        return launch_rgb_tile(st, L, P, G, depth, mode, stats, queue);
     if (!vec_ok) {
         if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
         // grid-stride; enough blocks to fill 256 CUs x 8
@@ -490,7 +490,7 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
 
 const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const YuvConsts &K,
                        const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy, int mode,
-                       unsigned *stats)
+                       unsigned *stats, unsigned *queue)
 {
     const int win = din > 8, wout = dout > 8;
     const int pxt = win ? 8 : 16;
@@ -504,7 +504,7 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
                          planes_aligned(P, 2, cbytes, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
     if (vec_ok && (variant == VAR_AUTO || variant == VAR_VEC_LDS))
-        return launch_yuv_tile(st, L, K, P, G, win, csx, csy, mode, stats);
+        return launch_yuv_tile(st, L, K, P, G, win, csx, csy, mode, stats, queue);
     if (!vec_ok) {
         if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
         const long long blocks = (long long)((G.w + (1 << csx) - 1) >> csx) * ((G.rows + bh - 1) >> csy) * G.nframes;

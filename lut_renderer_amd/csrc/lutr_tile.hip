@@ -25,9 +25,11 @@
 //
 // Arithmetic is the strict restatement (see lutr_kernels.hip): -ffp-contract=off, FFmpeg's
 // scalar C order, bit-identical to the oracle.
+#include <cstdio>
 #include <cstdlib>
 
 #include "lutr_internal.h"
+
 
 namespace lutr {
 
@@ -99,9 +101,11 @@ template <bool LDS, int INTERP>
 __device__ __forceinline__ PxC px_coords(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
 {
     const float xr = rc * L.scale_f, xg = gc * L.scale_f, xb = bc * L.scale_f;
-    const float sr = tmed3(xr * L.sc[0], 0.0f, L.lut_max);
-    const float sg = tmed3(xg * L.sc[1], 0.0f, L.lut_max);
-    const float sb = tmed3(xb * L.sc[2], 0.0f, L.lut_max);
+    // clipf(x*scale, 0, lut_max): codes and scales are >= 0, so only the upper bound can bind and a
+    // plain v_min_f32 (full rate) replaces v_med3_f32 (0.62x rate on gfx950, tools/ubench/op_rates.hip)
+    const float sr = fminf(xr * L.sc[0], L.lut_max);
+    const float sg = fminf(xg * L.sc[1], L.lut_max);
+    const float sb = fminf(xb * L.sc[2], L.lut_max);
     float pr, pg, pb;
     if constexpr (INTERP == LUTR_INTERP_NEAREST) {
         pr = floorf(sr + .5f); pg = floorf(sg + .5f); pb = floorf(sb + .5f);
@@ -336,6 +340,9 @@ __device__ __forceinline__ void fence_words(uint32_t *w)
 }
 
 __device__ __forceinline__ float cfloor(float v, float hi) { return tmed3(floorf(v), 0.0f, hi); }
+// RGB -> YUV side: Y and chroma are positive-offset convex mixes of codes in [0, M], so they cannot go
+// below 0; only full-range chroma can reach M+1 (128.5 + 127.5 at 8 bit).  Upper bound only.
+__device__ __forceinline__ float ofloor(float v, float hi) { return fminf(floorf(v), hi); }
 
 // ---------------------------------------------------------------- tile geometry
 struct TileGeom {
@@ -343,12 +350,15 @@ struct TileGeom {
     int uw, urows;        // units per row, unit rows (a unit = PXT px x BH rows)
     int nsx, nry;         // tiles across, tiles down
     int tiles;            // nframes * nsx * nry
-    int seg, nrs;         // a wave owns `seg` consecutive tile rows of one strip; nrs = segments down a frame
-    int waves;            // nframes * nrs * nsx; wave id = (frame * nrs + segment) * nsx + strip, so the
-                          // waves running side by side cover the SAME rows (shared DRAM pages / TLB entries)
-    int tiles_per_wave;
+    // Work is handed out in CHUNKS of `ch` consecutive tile rows of one strip.  Chunk id =
+    // (frame * nrc + row_chunk) * nsx + strip, so chunks claimed at about the same time are
+    // neighbouring strips of the same rows (shared DRAM pages).  Waves claim chunks from `queue`
+    // (one atomicAdd per chunk): tiles on colour edges cost 2-4x a plain tile and a static split
+    // left the slowest wave at 1.76x the mean.
+    int ch, nrc, nchunks;
+    unsigned *queue;      // device counter, zeroed by the launcher before every launch
     int win_nodes;        // LDS window capacity per wave, in 16-byte nodes
-    unsigned *stats;      // optional device counters (see stat_add); nullptr = off
+    unsigned *stats;      // optional device counters; nullptr = off
 };
 
 // ================================================================= fused YUV tile kernel
@@ -419,13 +429,13 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
         for (int p = 0; p < 4; p++) {
             const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
             rs[c] += o[p].r; gs[c] += o[p].g; bs[c] += o[p].b;
-            wput<WIDE>(out.y[dy], i, cfloor(tfma(K.cyr, o[p].r, tfma(K.cyg, o[p].g, tfma(K.cyb, o[p].b, K.yob))), K.max_o));
+            wput<WIDE>(out.y[dy], i, ofloor(tfma(K.cyr, o[p].r, tfma(K.cyg, o[p].g, tfma(K.cyb, o[p].b, K.yob))), K.max_o));
         }
 #pragma unroll
         for (int c = 0; c < NCG; c++) {
             const int j = g * NCG + c;
-            wput<WIDE>(out.cb, j, cfloor(tfma(K.cbr, rs[c], tfma(K.cbg, gs[c], tfma(K.cbb, bs[c], K.cob))), K.max_o));
-            wput<WIDE>(out.cr, j, cfloor(tfma(K.crr, rs[c], tfma(K.crg, gs[c], tfma(K.crb, bs[c], K.cob))), K.max_o));
+            wput<WIDE>(out.cb, j, ofloor(tfma(K.cbr, rs[c], tfma(K.cbg, gs[c], tfma(K.cbb, bs[c], K.cob))), K.max_o));
+            wput<WIDE>(out.cr, j, ofloor(tfma(K.crr, rs[c], tfma(K.crg, gs[c], tfma(K.crb, bs[c], K.cob))), K.max_o));
         }
         // emit the unit group by group (see fence_words)
         fence_words<T::YW * T::BH>(&in.y[0][0]);
@@ -444,6 +454,23 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
 #define LUTR_TILE_WAVES_PER_EU 4
 #endif
 
+// Claim the next chunk for this wave; returns false when the queue is drained.
+__device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &fr, int &sx, int &ry, int &rem)
+{
+    unsigned c = 0;
+    if (lane == 0) c = atomicAdd(TG.queue, 1u);
+    c = (unsigned)uni((int)c);
+    if (c >= (unsigned)TG.nchunks) return false;
+    const int per_frame = TG.nrc * TG.nsx;
+    fr = (int)c / per_frame;
+    const int r = (int)c - fr * per_frame;
+    const int rc = r / TG.nsx;
+    sx = r - rc * TG.nsx;
+    ry = rc * TG.ch;
+    rem = min(TG.ch, TG.nry - ry);
+    return true;
+}
+
 template <int WIDE, int CSX, int CSY, int INTERP, bool PRE>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
 void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
@@ -452,15 +479,9 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int wave = blockIdx.x * 4 + wib;
-    if (wave >= TG.waves) return;                             // wave-uniform; no barrier is ever used
     const int slice_off = wib * TG.win_nodes * 16;
-    // wave id -> (frame, row segment, strip); the wave walks DOWN its strip inside the segment
-    int fr = wave / (TG.nrs * TG.nsx);
-    const int rem = wave - fr * (TG.nrs * TG.nsx);
-    const int seg_i = rem / TG.nsx;
-    int sx = rem - seg_i * TG.nsx, ry = seg_i * TG.seg;
-    int t = 0;
-    const int t_end = uni(min(TG.seg, TG.nry - ry));
+    int fr, sx, ry, rem;                                      // the tile being fetched next
+    if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
@@ -490,13 +511,17 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     T nxt;
     load_tile(nxt, fr, sx, ry);
-    for (; t < t_end; t++) {
+    for (bool more = true; more;) {
         T in = nxt;
         const int cfr = fr, csx = sx, cry = ry;
-        // advance to the next tile and issue its loads NOW: vmcnt retires in order, so loads issued
-        // after this tile's stores would wait for those stores to be acknowledged by HBM
-        ry++;
-        if (t + 1 < t_end) load_tile(nxt, fr, sx, ry);
+        // Next tile: the one below in this chunk, else the first tile of a newly claimed chunk.  Its loads
+        // are issued NOW, before this tile's stores: vmcnt retires in order, so loads issued after the
+        // stores would wait for HBM to acknowledge them.  When the queue is drained the current tile is
+        // simply fetched again, so every path has the same number of memory operations in flight and
+        // hipcc can wait with a counted vmcnt instead of vmcnt(0).
+        if (--rem > 0) ry++;
+        else more = claim_chunk(TG, lane, fr, sx, ry, rem);
+        load_tile(nxt, fr, sx, ry);
 
         T out;
         Bnd bn;
@@ -510,6 +535,7 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
                 if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
                 else ws.n[3]++;
                 load_tile(in, cfr, csx, cry);          // the failed pass consumed the tile; L2 still has it
+                __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0) HERE, or the loop header waits on every pass
             } else {
                 yuv_tile_body<false, WIDE, CSX, CSY, INTERP, PRE>(L, K, WG, in, out, bn);
                 ws.n[2]++;
@@ -519,23 +545,27 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
             }
         }
         {
-            const int xu = csx * lw + lx, yu = (cry << lh_log2) + ly;
-            const bool active = xu < TG.uw && yu < TG.urows;
+            // Idle lanes of edge tiles processed a duplicate of a valid unit of this tile (load_tile clamps),
+            // so they store the same bytes to the same place as its owner: no branch, fixed store count.
+            const int lxc = min(lx, TG.uw - 1 - csx * lw), lyc = min(ly, TG.urows - 1 - (cry << lh_log2));
             const long long urow0 = cr0 + (cry << lh_log2);
             uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * P.ds[0] + (long long)csx * lw * YWB;
             uint8_t *dcb = P.d[1] + cfr * P.dfs[1] + urow0 * P.ds[1] + (long long)csx * lw * CWB;
             uint8_t *dcr = P.d[2] + cfr * P.dfs[2] + urow0 * P.ds[2] + (long long)csx * lw * CWB;
-            if (active) {
 #pragma unroll
-                for (int dy = 0; dy < T::BH; dy++)
-                    stw<T::YW>(dy_ + (unsigned)((ly * T::BH + dy) * (int)P.ds[0] + lx * YWB), out.y[dy]);
-                stw<T::CW>(dcb + (unsigned)(ly * (int)P.ds[1] + lx * CWB), out.cb);
-                stw<T::CW>(dcr + (unsigned)(ly * (int)P.ds[2] + lx * CWB), out.cr);
-            }
+            for (int dy = 0; dy < T::BH; dy++)
+                stw<T::YW>(dy_ + (unsigned)((lyc * T::BH + dy) * (int)P.ds[0] + lxc * YWB), out.y[dy]);
+            stw<T::CW>(dcb + (unsigned)(lyc * (int)P.ds[1] + lxc * CWB), out.cb);
+            stw<T::CW>(dcr + (unsigned)(lyc * (int)P.ds[2] + lxc * CWB), out.cr);
         }
         ws.n[0]++;
     }
     ws.flush(TG.stats, lane);
+    if (TG.stats && lane == 0) {                           // load balance: longest and summed wave lifetimes (100 MHz ticks)
+        const unsigned life = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
+        atomicMax(&TG.stats[10], life);
+        atomicAdd(&TG.stats[11], life >> 6);
+    }
     if (TG.stats && lane == 0 && (wave & 255) == 0) {      // a few waves report their clock: cycles / 100 MHz ticks
         atomicAdd(&TG.stats[4], (unsigned)((__builtin_amdgcn_s_memtime() - clk0) >> 8));
         atomicAdd(&TG.stats[5], (unsigned)((__builtin_amdgcn_s_memrealtime() - rt0) >> 8));
@@ -576,15 +606,9 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int wave = blockIdx.x * 4 + wib;
-    if (wave >= TG.waves) return;                             // wave-uniform; no barrier is ever used
     const int slice_off = wib * TG.win_nodes * 16;
-    // wave id -> (frame, row segment, strip); the wave walks DOWN its strip inside the segment
-    int fr = wave / (TG.nrs * TG.nsx);
-    const int rem = wave - fr * (TG.nrs * TG.nsx);
-    const int seg_i = rem / TG.nsx;
-    int sx = rem - seg_i * TG.nsx, ry = seg_i * TG.seg;
-    int t = 0;
-    const int t_end = uni(min(TG.seg, TG.nry - ry));
+    int fr, sx, ry, rem;                                      // the tile being fetched next
+    if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
 
@@ -606,11 +630,12 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
     WaveStats ws;
     T nxt;
     load_tile(nxt, fr, sx, ry);
-    for (; t < t_end; t++) {
+    for (bool more = true; more;) {
         T in = nxt;
         const int cfr = fr, csx = sx, cry = ry;
-        ry++;
-        if (t + 1 < t_end) load_tile(nxt, fr, sx, ry);             // before this tile's stores (in-order vmcnt)
+        if (--rem > 0) ry++;                    // next tile of the chunk, or a new chunk (see k_yuv_tile)
+        else more = claim_chunk(TG, lane, fr, sx, ry, rem);
+        load_tile(nxt, fr, sx, ry);
 
         T out;
         Bnd bn;
@@ -623,6 +648,7 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
                 if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
                 else ws.n[3]++;
                 load_tile(in, cfr, csx, cry);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
             } else {
                 rgb_tile_body<false, WIDE, INTERP>(L, WG, in, out, bn);
                 ws.n[2]++;
@@ -631,15 +657,12 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
             }
         }
         {
-            const int xu = csx * lw + lx, yu = (cry << lh_log2) + ly;
-            const bool active = xu < TG.uw && yu < TG.urows;
+            const int lxc = min(lx, TG.uw - 1 - csx * lw), lyc = min(ly, TG.urows - 1 - (cry << lh_log2));
             const long long row0 = G.row0 + (cry << lh_log2);
             const long long xb = (long long)csx * lw * 16;
-            if (active) {
-                stw<4>(P.d[0] + cfr * P.dfs[0] + row0 * P.ds[0] + xb + (unsigned)(ly * (int)P.ds[0] + lx * 16), out.g);
-                stw<4>(P.d[1] + cfr * P.dfs[1] + row0 * P.ds[1] + xb + (unsigned)(ly * (int)P.ds[1] + lx * 16), out.b);
-                stw<4>(P.d[2] + cfr * P.dfs[2] + row0 * P.ds[2] + xb + (unsigned)(ly * (int)P.ds[2] + lx * 16), out.r);
-            }
+            stw<4>(P.d[0] + cfr * P.dfs[0] + row0 * P.ds[0] + xb + (unsigned)(lyc * (int)P.ds[0] + lxc * 16), out.g);
+            stw<4>(P.d[1] + cfr * P.dfs[1] + row0 * P.ds[1] + xb + (unsigned)(lyc * (int)P.ds[1] + lxc * 16), out.b);
+            stw<4>(P.d[2] + cfr * P.dfs[2] + row0 * P.ds[2] + xb + (unsigned)(lyc * (int)P.ds[2] + lxc * 16), out.r);
         }
         ws.n[0]++;
     }
@@ -663,9 +686,11 @@ static int device_cus()
 
 // Split the 64 lanes of a wave between x (units of one row) and y (unit rows) so that a
 // row of `uw` units wastes as few lanes as possible; prefer wide tiles (longer bursts).
-static void plan_tiles(TileGeom *tg, int uw, int urows, int nframes, int win_nodes, int waves_per_cu, unsigned *stats)
+static void plan_tiles(TileGeom *tg, int uw, int urows, int nframes, int win_nodes, int waves_per_cu, unsigned *stats,
+                       unsigned *queue)
 {
     tg->stats = stats;
+    tg->queue = queue;
     int best = 6;
     double best_eff = -1.0;
     for (int l = 6; l >= 2; l--) {
@@ -679,22 +704,25 @@ static void plan_tiles(TileGeom *tg, int uw, int urows, int nframes, int win_nod
     tg->nsx = (uw + (1 << best) - 1) >> best;
     tg->nry = (urows + (64 >> best) - 1) / (64 >> best);
     tg->tiles = nframes * tg->nsx * tg->nry;
+    // chunk height: 16 tile rows (a staged window is reused ~15 times), shorter for small jobs so that
+    // every resident wave gets work
     const int max_waves = device_cus() * waves_per_cu;
-    // row segments: enough waves to fill the chip once when the job allows, at least 2 tiles per wave
-    // so a staged window is reused
-    long long strips = (long long)nframes * tg->nsx;
-    int nrs = (int)(max_waves / strips);                     // floor: never more waves than fit at once
-    if (nrs < 1) nrs = 1;
-    if (nrs > (tg->nry + 3) / 4) nrs = (tg->nry + 3) / 4;    // >= 4 tiles per wave: a staged window gets reused
-    if (nrs < 1) nrs = 1;
-    tg->seg = (tg->nry + nrs - 1) / nrs;
-    tg->nrs = (tg->nry + tg->seg - 1) / tg->seg;
-    tg->waves = nframes * tg->nrs * tg->nsx;
-    tg->tiles_per_wave = tg->seg;
+    int ch = 16;
+    if (const char *e = getenv("LUTR_CHUNK")) { const int v = atoi(e); if (v >= 2 && v <= 256) ch = v; }
+    while (ch > 2 && (long long)nframes * tg->nsx * ((tg->nry + ch - 1) / ch) < 2ll * max_waves) ch >>= 1;
+    tg->ch = ch;
+    tg->nrc = (tg->nry + ch - 1) / ch;
+    tg->nchunks = nframes * tg->nrc * tg->nsx;
     tg->win_nodes = win_nodes;
 }
 
-static int tile_blocks(const TileGeom &tg) { return (tg.waves + 3) / 4; }
+// persistent grid: as many waves as fit on the chip, or one per chunk if there are fewer chunks
+static int tile_blocks(const TileGeom &tg, int waves_per_cu)
+{
+    const int max_waves = device_cus() * waves_per_cu;
+    const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
+    return (waves + 3) / 4;
+}
 
 static int g_win_nodes = 640;       // 10 KB per wave, 40 KB per 256-thread block, 4 blocks per CU = all 160 KB
 static int g_waves_per_cu = 16;
@@ -715,13 +743,14 @@ void tile_tuning(int win_nodes, int waves_per_cu)
 }
 
 const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G, int depth, int mode,
-                            unsigned *stats)
+                            unsigned *stats, unsigned *queue)
 {
     const int wide = depth > 8, pxt = wide ? 8 : 16;
     TileGeom tg;
     read_env_tuning();
-    plan_tiles(&tg, G.w / pxt, G.rows, G.nframes, g_win_nodes, g_waves_per_cu, stats);
-    const dim3 grid(tile_blocks(tg)), block(256);
+    plan_tiles(&tg, G.w / pxt, G.rows, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
+    if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
+    const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(256);
     const size_t lds = (size_t)4 * tg.win_nodes * 16;
 #define RGB_CASE(W, I) \
     if (wide == W && mode == I) { \
@@ -735,15 +764,22 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
 }
 
 const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
-                            const FrameGeom &G, int win, int csx, int csy, int mode, unsigned *stats)
+                            const FrameGeom &G, int win, int csx, int csy, int mode, unsigned *stats, unsigned *queue)
 {
     const int pxt = (win ? 8 : 16) >> LUTR_UNIT_HALF;
     TileGeom tg;
     read_env_tuning();
-    plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats);
-    const dim3 grid(tile_blocks(tg)), block(256);
+    plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
+    if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
+    const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(256);
     const size_t lds = (size_t)4 * tg.win_nodes * 16;
     const bool pre = K.pre != 0.0f;
+    if (getenv("LUTR_DEBUG")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false>, 256, lds);
+        fprintf(stderr, "[lutr] tiles %d nsx %d nry %d chunk %d nrc %d chunks %d blocks %u lds/block %zu occupancy(blocks/CU) %d cus %d\n",
+                tg.tiles, tg.nsx, tg.nry, tg.ch, tg.nrc, tg.nchunks, grid.x, lds, nb, device_cus());
+    }
 #define YUV_CASE(W, X, Y, I) \
     if (win == W && csx == X && csy == Y && mode == I) { \
         if (pre) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true>), grid, block, lds, st, L, K, P, G, tg); \
