@@ -97,21 +97,45 @@ struct PxC {
     float w0, w1, w2, w3;   // tetrahedral weights; trilinear keeps d.r, d.g, d.b in w0..w2
 };
 
-template <bool LDS, int INTERP>
-__device__ __forceinline__ PxC px_coords(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
+// (prev, frac) of one channel.  Computed form: FFmpeg's float ops on the code (A.3).  Table form:
+// the same ops were applied once per code when the kernel started (coord_table_fill), one
+// ds_read_b64 fetches the pair.  Both give identical bits.
+struct Crd { float p, d; };
+
+template <int INTERP>
+__device__ __forceinline__ Crd crd_compute(const LutConsts &L, float code, float sc)
 {
-    const float xr = rc * L.scale_f, xg = gc * L.scale_f, xb = bc * L.scale_f;
+    const float x = code * L.scale_f;
     // clipf(x*scale, 0, lut_max): codes and scales are >= 0, so only the upper bound can bind and a
     // plain v_min_f32 (full rate) replaces v_med3_f32 (0.62x rate on gfx950, tools/ubench/op_rates.hip)
-    const float sr = fminf(xr * L.sc[0], L.lut_max);
-    const float sg = fminf(xg * L.sc[1], L.lut_max);
-    const float sb = fminf(xb * L.sc[2], L.lut_max);
-    float pr, pg, pb;
-    if constexpr (INTERP == LUTR_INTERP_NEAREST) {
-        pr = floorf(sr + .5f); pg = floorf(sg + .5f); pb = floorf(sb + .5f);
-    } else {
-        pr = floorf(sr); pg = floorf(sg); pb = floorf(sb);
+    const float s = fminf(x * sc, L.lut_max);
+    Crd c;
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) { c.p = floorf(s + .5f); c.d = 0.0f; }
+    else { c.p = floorf(s); c.d = s - c.p; }
+    return c;
+}
+
+__device__ __forceinline__ Crd crd_table(unsigned code)
+{
+    const float2 e = *(const float2 *)(lutr_smem + code * 8u);
+    return Crd{e.x, e.y};
+}
+
+// All 256 threads of the block fill the per-code table at LDS offset 0 (before any wave claims work).
+template <int INTERP>
+__device__ __forceinline__ void coord_table_fill(const LutConsts &L, int entries)
+{
+    for (int q = threadIdx.x; q < entries; q += 256) {
+        const Crd c = crd_compute<INTERP>(L, (float)q, L.sc[0]);
+        *(float2 *)(lutr_smem + q * 8) = make_float2(c.p, c.d);
     }
+    __syncthreads();
+}
+
+template <bool LDS, int INTERP>
+__device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const Crd &cr, const Crd &cg, const Crd &cb, Bnd &bn)
+{
+    const float pr = cr.p, pg = cg.p, pb = cb.p;
     {   // bounds in sheared coordinates
         const float hg = pg - pr, hb = pb - pr;
         bn.rmin = fminf(bn.rmin, pr); bn.rmax = fmaxf(bn.rmax, pr);
@@ -129,11 +153,11 @@ __device__ __forceinline__ PxC px_coords(const LutConsts &L, const Win &W, float
     c.oa = c.oz = 0;
     c.w0 = c.w1 = c.w2 = c.w3 = 0.0f;
     if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
-        c.w0 = sr - pr; c.w1 = sg - pg; c.w2 = sb - pb;
+        c.w0 = cr.d; c.w1 = cg.d; c.w2 = cb.d;
     } else if constexpr (INTERP == LUTR_INTERP_TETRAHEDRAL) {
         // sorted form (see lutr_kernels.hip interp_tetrahedral for why this is bit-identical to
         // FFmpeg's six branches on a finite lattice)
-        const float dr = sr - pr, dg = sg - pg, db = sb - pb;
+        const float dr = cr.d, dg = cg.d, db = cb.d;
         const float x = fmaxf(fmaxf(dr, dg), db), y = tmed3(dr, dg, db), z = fminf(fminf(dr, dg), db);
         const bool rg = dr > dg, gb = dg > db, rb = dr > db;
         // by-value copies: a ?: over struct members is an lvalue select, which pins W in scratch
@@ -146,6 +170,21 @@ __device__ __forceinline__ PxC px_coords(const LutConsts &L, const Win &W, float
         c.w0 = 1.0f - x; c.w1 = x - y; c.w2 = y - z; c.w3 = z;
     }
     return c;
+}
+
+// float codes (already clipped to [0, M]) -> PxC, computed coordinates
+template <bool LDS, int INTERP>
+__device__ __forceinline__ PxC px_coords(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
+{
+    return px_finish<LDS, INTERP>(L, W, crd_compute<INTERP>(L, rc, L.sc[0]), crd_compute<INTERP>(L, gc, L.sc[1]),
+                                  crd_compute<INTERP>(L, bc, L.sc[2]), bn);
+}
+
+// integer codes in [0, M] -> PxC, table coordinates
+template <bool LDS, int INTERP>
+__device__ __forceinline__ PxC px_coords_tab(const LutConsts &L, const Win &W, unsigned ri, unsigned gi, unsigned bi, Bnd &bn)
+{
+    return px_finish<LDS, INTERP>(L, W, crd_table(ri), crd_table(gi), crd_table(bi), bn);
 }
 
 template <bool LDS, int INTERP>
@@ -358,6 +397,7 @@ struct TileGeom {
     int ch, nrc, nchunks;
     unsigned *queue;      // device counter, zeroed by the launcher before every launch
     int win_nodes;        // LDS window capacity per wave, in 16-byte nodes
+    int tab_bytes;        // per-code coordinate table at LDS offset 0 (0 = coordinates are computed)
     unsigned *stats;      // optional device counters; nullptr = off
 };
 
@@ -378,7 +418,7 @@ struct YuvTile {
     uint32_t y[BH][YW], cb[CW], cr[CW];
 };
 
-template <bool LDS, int WIDE, int CSX, int CSY, int INTERP, bool PRE>
+template <bool LDS, int WIDE, int CSX, int CSY, int INTERP, bool PRE, bool TAB>
 __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConsts &K, const Win &W,
                                               YuvTile<WIDE, CSX, CSY> &in, YuvTile<WIDE, CSX, CSY> &out, Bnd &bn)
 {
@@ -415,8 +455,16 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
             float yv = wsample<WIDE>(in.y[dy], i);
             if constexpr (PRE) yv = cfloor(tfma(K.py, yv, K.pyb), K.pre_max);
             const float yy = tfma(K.ky, yv, K.yb);
-            const float rq = cfloor(yy + rv[c], K.max_l), gq = cfloor(yy + gv[c], K.max_l), bq = cfloor(yy + bu[c], K.max_l);
-            pc[p] = px_coords<LDS, INTERP>(L, W, rq, gq, bq, bn);
+            if constexpr (TAB) {
+                // clip(floor(v), 0, M) as an integer: v_cvt_u32_f32 truncates and saturates negatives to 0
+                const unsigned mi = (unsigned)K.max_l;
+                const unsigned ri = min((unsigned)(yy + rv[c]), mi), gi = min((unsigned)(yy + gv[c]), mi),
+                               bi = min((unsigned)(yy + bu[c]), mi);
+                pc[p] = px_coords_tab<LDS, INTERP>(L, W, ri, gi, bi, bn);
+            } else {
+                const float rq = cfloor(yy + rv[c], K.max_l), gq = cfloor(yy + gv[c], K.max_l), bq = cfloor(yy + bu[c], K.max_l);
+                pc[p] = px_coords<LDS, INTERP>(L, W, rq, gq, bq, bn);
+            }
         }
         // ---- stage B: taps and blend (pairs keep 8 reads in flight), stage C: outputs
         Rgb3 o[4];
@@ -471,22 +519,23 @@ __device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &f
     return true;
 }
 
-template <int WIDE, int CSX, int CSY, int INTERP, bool PRE>
+template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, bool TAB>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
 void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
 {
+    if constexpr (TAB) coord_table_fill<INTERP>(L, TG.tab_bytes / 8);     // the kernel's only barrier
     using T = YuvTile<WIDE, CSX, CSY>;
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int wave = blockIdx.x * 4 + wib;
-    const int slice_off = wib * TG.win_nodes * 16;
+    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * 16;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
 
-    const int lds_bytes = 4 * TG.win_nodes * 16;
+    const int lds_bytes = TG.tab_bytes + 4 * TG.win_nodes * 16;
     Win W, WG;
     win_empty(W, slice_off);
     win_global(WG, L);
@@ -528,7 +577,7 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
         for (;;) {
             bnd_reset(bn);
             if (lds_mode) {
-                yuv_tile_body<true, WIDE, CSX, CSY, INTERP, PRE>(L, K, W, in, out, bn);
+                yuv_tile_body<true, WIDE, CSX, CSY, INTERP, PRE, TAB>(L, K, W, in, out, bn);
                 if (win_holds(W, bn)) break;
                 // miss: re-stage around this tile's colours and redo it, or give the tile to the gather body
                 ws.n[1]++;
@@ -537,7 +586,7 @@ void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
                 load_tile(in, cfr, csx, cry);          // the failed pass consumed the tile; L2 still has it
                 __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0) HERE, or the loop header waits on every pass
             } else {
-                yuv_tile_body<false, WIDE, CSX, CSY, INTERP, PRE>(L, K, WG, in, out, bn);
+                yuv_tile_body<false, WIDE, CSX, CSY, INTERP, PRE, TAB>(L, K, WG, in, out, bn);
                 ws.n[2]++;
                 // colours narrow enough again?  then the next tile starts from a staged window
                 if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
@@ -579,7 +628,14 @@ struct RgbTile {
     uint32_t g[4], b[4], r[4];
 };
 
-template <bool LDS, int WIDE, int INTERP>
+template <int WIDE>
+__device__ __forceinline__ unsigned wcode(const uint32_t *w, int i)
+{
+    if constexpr (WIDE) return (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+    else return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+}
+
+template <bool LDS, int WIDE, int INTERP, bool TAB>
 __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, RgbTile<WIDE> &in,
                                               RgbTile<WIDE> &out, Bnd &bn)
 {
@@ -587,7 +643,16 @@ __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, 
     for (int k = 0; k < 4; k++) { out.g[k] = 0; out.b[k] = 0; out.r[k] = 0; }
 #pragma unroll
     for (int i = 0; i < RgbTile<WIDE>::PXT; i++) {
-        const Rgb3 o = lut_px<LDS, INTERP>(L, W, wsample<WIDE>(in.r, i), wsample<WIDE>(in.g, i), wsample<WIDE>(in.b, i), bn);
+        Rgb3 o;
+        if constexpr (TAB) {
+            // codes above 2^depth-1 cannot occur in a valid plane; clamp so a stray one cannot index past the table
+            const unsigned mi = (unsigned)L.maxf;
+            const PxC c = px_coords_tab<LDS, INTERP>(L, W, min(wcode<WIDE>(in.r, i), mi), min(wcode<WIDE>(in.g, i), mi),
+                                                     min(wcode<WIDE>(in.b, i), mi), bn);
+            o = px_quant(L, px_blend<LDS, INTERP>(L, W, c));
+        } else {
+            o = lut_px<LDS, INTERP>(L, W, wsample<WIDE>(in.r, i), wsample<WIDE>(in.g, i), wsample<WIDE>(in.b, i), bn);
+        }
         wput<WIDE>(out.g, i, o.g);
         wput<WIDE>(out.b, i, o.b);
         wput<WIDE>(out.r, i, o.r);
@@ -598,21 +663,22 @@ __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, 
     }
 }
 
-template <int WIDE, int INTERP>
+template <int WIDE, int INTERP, bool TAB>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
 void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
 {
+    if constexpr (TAB) coord_table_fill<INTERP>(L, TG.tab_bytes / 8);
     using T = RgbTile<WIDE>;
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int wave = blockIdx.x * 4 + wib;
-    const int slice_off = wib * TG.win_nodes * 16;
+    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * 16;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
 
-    const int lds_bytes = 4 * TG.win_nodes * 16;
+    const int lds_bytes = TG.tab_bytes + 4 * TG.win_nodes * 16;
     Win W, WG;
     win_empty(W, slice_off);
     win_global(WG, L);
@@ -642,7 +708,7 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
         for (;;) {
             bnd_reset(bn);
             if (lds_mode) {
-                rgb_tile_body<true, WIDE, INTERP>(L, W, in, out, bn);
+                rgb_tile_body<true, WIDE, INTERP, TAB>(L, W, in, out, bn);
                 if (win_holds(W, bn)) break;
                 ws.n[1]++;
                 if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
@@ -650,7 +716,7 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
                 load_tile(in, cfr, csx, cry);
                 __builtin_amdgcn_s_waitcnt(0x0f70);
             } else {
-                rgb_tile_body<false, WIDE, INTERP>(L, WG, in, out, bn);
+                rgb_tile_body<false, WIDE, INTERP, TAB>(L, WG, in, out, bn);
                 ws.n[2]++;
                 if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
                 break;
@@ -704,12 +770,12 @@ static void plan_tiles(TileGeom *tg, int uw, int urows, int nframes, int win_nod
     tg->nsx = (uw + (1 << best) - 1) >> best;
     tg->nry = (urows + (64 >> best) - 1) / (64 >> best);
     tg->tiles = nframes * tg->nsx * tg->nry;
-    // chunk height: 16 tile rows (a staged window is reused ~15 times), shorter for small jobs so that
-    // every resident wave gets work
+    // chunk height: 16 tile rows (a staged window is reused ~15 times); only jobs too small to give
+    // half the resident waves a chunk get shorter chunks (each chunk start costs a window miss)
     const int max_waves = device_cus() * waves_per_cu;
     int ch = 16;
     if (const char *e = getenv("LUTR_CHUNK")) { const int v = atoi(e); if (v >= 2 && v <= 256) ch = v; }
-    while (ch > 2 && (long long)nframes * tg->nsx * ((tg->nry + ch - 1) / ch) < 2ll * max_waves) ch >>= 1;
+    while (ch > 4 && (long long)nframes * tg->nsx * ((tg->nry + ch - 1) / ch) < max_waves / 2) ch >>= 1;
     tg->ch = ch;
     tg->nrc = (tg->nry + ch - 1) / ch;
     tg->nchunks = nframes * tg->nrc * tg->nsx;
@@ -742,6 +808,18 @@ void tile_tuning(int win_nodes, int waves_per_cu)
     if (waves_per_cu >= 4) g_waves_per_cu = waves_per_cu;
 }
 
+// The per-code coordinate table needs equal per-channel scales (one table serves R, G and B) and a
+// depth of at most 10 bits (8 KB); the window shrinks so that 4 blocks still share the CU's 160 KB.
+static int plan_table(TileGeom *tg, const LutConsts &L)
+{
+    const int entries = (int)L.maxf + 1;
+    const bool ok = L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2] && entries <= 1024 && !getenv("LUTR_NO_TAB");
+    tg->tab_bytes = ok ? entries * 8 : 0;
+    const int cap = (40960 - tg->tab_bytes) / 64;                // nodes per wave with 4 blocks of 4 waves per CU
+    if (tg->tab_bytes && tg->win_nodes > cap) tg->win_nodes = cap;
+    return tg->tab_bytes;
+}
+
 const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G, int depth, int mode,
                             unsigned *stats, unsigned *queue)
 {
@@ -751,11 +829,13 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     plan_tiles(&tg, G.w / pxt, G.rows, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
     if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(256);
-    const size_t lds = (size_t)4 * tg.win_nodes * 16;
+    const bool tab = plan_table(&tg, L) != 0;
+    const size_t lds = (size_t)tg.tab_bytes + (size_t)4 * tg.win_nodes * 16;
 #define RGB_CASE(W, I) \
     if (wide == W && mode == I) { \
-        hipLaunchKernelGGL((k_rgb_tile<W, I>), grid, block, lds, st, L, P, G, tg); \
-        return "k_rgb_tile<" #W "," #I ">"; \
+        if (tab) hipLaunchKernelGGL((k_rgb_tile<W, I, true>), grid, block, lds, st, L, P, G, tg); \
+        else hipLaunchKernelGGL((k_rgb_tile<W, I, false>), grid, block, lds, st, L, P, G, tg); \
+        return tab ? "k_rgb_tile<" #W "," #I ",tab>" : "k_rgb_tile<" #W "," #I ">"; \
     }
     RGB_CASE(0, 0) RGB_CASE(0, 1) RGB_CASE(0, 2)
     RGB_CASE(1, 0) RGB_CASE(1, 1) RGB_CASE(1, 2)
@@ -772,19 +852,23 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
     if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(256);
-    const size_t lds = (size_t)4 * tg.win_nodes * 16;
+    const bool tab = plan_table(&tg, L) != 0;
+    const size_t lds = (size_t)tg.tab_bytes + (size_t)4 * tg.win_nodes * 16;
     const bool pre = K.pre != 0.0f;
     if (getenv("LUTR_DEBUG")) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false>, 256, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false, true>, 256, lds);
         fprintf(stderr, "[lutr] tiles %d nsx %d nry %d chunk %d nrc %d chunks %d blocks %u lds/block %zu occupancy(blocks/CU) %d cus %d\n",
                 tg.tiles, tg.nsx, tg.nry, tg.ch, tg.nrc, tg.nchunks, grid.x, lds, nb, device_cus());
     }
 #define YUV_CASE(W, X, Y, I) \
     if (win == W && csx == X && csy == Y && mode == I) { \
-        if (pre) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true>), grid, block, lds, st, L, K, P, G, tg); \
-        else hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false>), grid, block, lds, st, L, K, P, G, tg); \
-        return pre ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"; \
+        if (pre && tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, true>), grid, block, lds, st, L, K, P, G, tg); \
+        else if (pre) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, false>), grid, block, lds, st, L, K, P, G, tg); \
+        else if (tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, true>), grid, block, lds, st, L, K, P, G, tg); \
+        else hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, false>), grid, block, lds, st, L, K, P, G, tg); \
+        return pre ? (tab ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre,tab>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre>") \
+                   : (tab ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"); \
     }
 #define YUV_FMT(W, X, Y) YUV_CASE(W, X, Y, 0) YUV_CASE(W, X, Y, 1) YUV_CASE(W, X, Y, 2)
     YUV_FMT(0, 1, 1) YUV_FMT(0, 1, 0) YUV_FMT(0, 0, 0)
