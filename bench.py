@@ -79,13 +79,22 @@ def barrier(world):
         dist.barrier()
 
 
+def apply(eng, pf, src, dst, fmt, interp):
+    if pf.family == "gbr":
+        return eng.apply_rgb(src, dst, depth=pf.depth, interp=interp)
+    return eng.apply_yuv(src, dst, pix_fmt=fmt, interp=interp)
+
+
 def build_batch(eng, pf, w, h, r0, r1, nframes, dist_name, unique):
     """Rows [r0,r1) of `unique` synthetic frames, tiled to `nframes` frames on the device."""
     from lut_renderer_amd import frames
     bh = 1 << pf.csy
     planes = [[], [], []]
     for k in range(unique):
-        f = frames.make_yuv(dist_name, w, h, pf.depth, pf.csx, pf.csy, k=k)
+        if pf.family == "gbr":
+            f = (frames.natural_rgb if dist_name == "natural" else frames.uniform_rgb)(w, h, pf.depth, k=k)
+        else:
+            f = frames.make_yuv(dist_name, w, h, pf.depth, pf.csx, pf.csy, k=k)
         sl = [f[0][r0:r1], f[1][r0 // bh:(r1 + bh - 1) // bh], f[2][r0 // bh:(r1 + bh - 1) // bh]]
         for i in range(3):
             a = np.ascontiguousarray(sl[i])
@@ -98,9 +107,9 @@ def build_batch(eng, pf, w, h, r0, r1, nframes, dist_name, unique):
     return out
 
 
-def time_steps(eng, src, dst, fmt, interp, steps, warmup, world):
+def time_steps(eng, pf, src, dst, fmt, interp, steps, warmup, world):
     for _ in range(warmup):
-        eng.apply_yuv(src, dst, pix_fmt=fmt, interp=interp)
+        apply(eng, pf, src, dst, fmt, interp)
     torch.cuda.synchronize()
     barrier(world)
     torch.cuda.synchronize()
@@ -108,7 +117,7 @@ def time_steps(eng, src, dst, fmt, interp, steps, warmup, world):
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(steps):
-        eng.apply_yuv(src, dst, pix_fmt=fmt, interp=interp)
+        apply(eng, pf, src, dst, fmt, interp)
     ev1.record()
     torch.cuda.synchronize()
     barrier(world)
@@ -123,13 +132,22 @@ def cpu_baseline(lut, pf, w, h, interp, dist_name, budget_s):
     from oracle import binding as orc
     cores = os.cpu_count() or 1
     # whole frames until the budget is spent (>= 2 repetitions); rows are split over `cores` threads
-    f = frames.make_yuv(dist_name, w, h, pf.depth, pf.csx, pf.csy, k=0)
-    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", pf.depth, pf.depth, pf.depth, 1 << (pf.csx + pf.csy))
-    orc.apply_yuv(lut.table, lut.scale, interp, k, pf.depth, pf.depth, pf.depth, pf.csx, pf.csy, f, nthreads=cores)
+    if pf.family == "gbr":
+        f = (frames.natural_rgb if dist_name == "natural" else frames.uniform_rgb)(w, h, pf.depth, k=0)
+
+        def run():
+            orc.apply_rgb(lut.table, lut.scale, pf.depth, interp, f, nthreads=cores)
+    else:
+        f = frames.make_yuv(dist_name, w, h, pf.depth, pf.csx, pf.csy, k=0)
+        k = orc.yuv_constants("bt709", "tv", "bt709", "tv", pf.depth, pf.depth, pf.depth, 1 << (pf.csx + pf.csy))
+
+        def run():
+            orc.apply_yuv(lut.table, lut.scale, interp, k, pf.depth, pf.depth, pf.depth, pf.csx, pf.csy, f,
+                          nthreads=cores)
+    run()
     n, t0 = 0, time.perf_counter()
     while True:
-        orc.apply_yuv(lut.table, lut.scale, interp, k, pf.depth, pf.depth, pf.depth, pf.csx, pf.csy, f,
-                      nthreads=cores)
+        run()
         n += 1
         el = time.perf_counter() - t0
         if n >= 2 and el >= budget_s:
@@ -180,13 +198,14 @@ def main():
     dst = [torch.empty_like(t) for t in src]
     px_rank = (r1 - r0) * w * nframes
 
-    wall, kern = time_steps(eng, src, dst, args.fmt, args.interp, args.steps, args.warmup, world)
+    wall, kern = time_steps(eng, pf, src, dst, args.fmt, args.interp, args.steps, args.warmup, world)
     kernel_name = eng.last_kernel
     tile_stats = None
     if "tile" in kernel_name:                    # one extra, untimed pass with the window counters armed
         eng.tile_stats(True)
-        eng.apply_yuv(src, dst, pix_fmt=args.fmt, interp=args.interp)
+        apply(eng, pf, src, dst, args.fmt, args.interp)
         tile_stats = eng.tile_stats(False)
+        tile_stats.pop("clock", None)
         if rank == 0:
             log(f"[tile stats] {tile_stats}")
     t = torch.tensor([wall, kern, float(px_rank)], dtype=torch.float64, device=eng.device)
@@ -205,16 +224,16 @@ def main():
         for dname in ("natural", "uniform"):
             for mode in ("tetrahedral", "trilinear"):
                 s2 = build_batch(eng, pf, w, h, r0, r1, nframes, dname, args.unique)
-                _, k2 = time_steps(eng, s2, dst, args.fmt, mode, max(3, args.steps // 2), 2, 1)
+                _, k2 = time_steps(eng, pf, s2, dst, args.fmt, mode, max(3, args.steps // 2), 2, 1)
                 extra[f"{dname}/{mode}"] = round(px_rank / k2 / 1e6, 1)
                 eng.tile_stats(True)
-                eng.apply_yuv(s2, dst, pix_fmt=args.fmt, interp=mode)
+                apply(eng, pf, s2, dst, args.fmt, mode)
                 log(f"[extra] {dname:8s} {mode:12s} {extra[f'{dname}/{mode}']:>12.1f} Mpx/s  ({eng.last_kernel}) "
                     f"{eng.tile_stats(False)}")
                 del s2
 
     if rank == 0:
-        bpp_in = (1.0 + 2.0 / (1 << (pf.csx + pf.csy))) * (1 if pf.depth <= 8 else 2)
+        bpp_in = (3.0 if pf.family == "gbr" else 1.0 + 2.0 / (1 << (pf.csx + pf.csy))) * (1 if pf.depth <= 8 else 2)
         bpp = 2.0 * bpp_in                                        # in + out, same format
         lattice_bytes = 3 * args.lut ** 3 * 4
         bytes_launch = bpp * px_rank + lattice_bytes              # per launch on one GPU

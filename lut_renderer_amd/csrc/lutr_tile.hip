@@ -54,6 +54,16 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// A wave-uniform constant used by many full-rate VOP2 ops per pixel is worth a VGPR: an SGPR source
+// operand drops v_mul/v_add/v_fmac to the 0.62x issue class on gfx950 (tools/ubench/op_rates.hip).
+// The asm makes the copy opaque so hipcc cannot fold it back into the SGPR.
+__device__ __forceinline__ float in_vgpr(float s)
+{
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
 // ---------------------------------------------------------------- window state (wave-uniform)
 struct Win {
     // byte address of the tap at cell (pr,pg,pb): (int) fma(pr, fr, fma(pg, fg, fma(pb, fb, fc)))
@@ -405,6 +415,9 @@ struct TileGeom {
 // A unit is what one lane handles per tile: PXT luma samples wide, BH rows tall.  With
 // LUTR_UNIT_HALF the unit is 8 bytes of luma per row instead of 16: half the input / output /
 // prefetch registers per lane (more waves per SIMD) at twice the per-tile overhead per pixel.
+#ifndef LUTR_PIN_CONSTS
+#define LUTR_PIN_CONSTS 0
+#endif
 #ifndef LUTR_UNIT_HALF
 #define LUTR_UNIT_HALF 0
 #endif
@@ -521,8 +534,14 @@ __device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &f
 
 template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, bool TAB>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
-void k_yuv_tile(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G, TileGeom TG)
+void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG)
 {
+    LutConsts L = L_;
+    YuvConsts K = K_;
+    if (LUTR_PIN_CONSTS) {      // used 3-6 times per pixel by full-rate ops
+        L.maxf = in_vgpr(L_.maxf);
+        K.cyr = in_vgpr(K_.cyr); K.cyg = in_vgpr(K_.cyg); K.cyb = in_vgpr(K_.cyb);
+    }
     if constexpr (TAB) coord_table_fill<INTERP>(L, TG.tab_bytes / 8);     // the kernel's only barrier
     using T = YuvTile<WIDE, CSX, CSY>;
     const int lane = threadIdx.x & 63;
@@ -639,27 +658,37 @@ template <bool LDS, int WIDE, int INTERP, bool TAB>
 __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, RgbTile<WIDE> &in,
                                               RgbTile<WIDE> &out, Bnd &bn)
 {
+    // `in` is consumed (see yuv_tile_body).  Groups of 4 pixels, staged: coordinates for all four,
+    // then taps + blend, then packing, so neighbouring instructions are independent.
 #pragma unroll
     for (int k = 0; k < 4; k++) { out.g[k] = 0; out.b[k] = 0; out.r[k] = 0; }
 #pragma unroll
-    for (int i = 0; i < RgbTile<WIDE>::PXT; i++) {
-        Rgb3 o;
-        if constexpr (TAB) {
-            // codes above 2^depth-1 cannot occur in a valid plane; clamp so a stray one cannot index past the table
-            const unsigned mi = (unsigned)L.maxf;
-            const PxC c = px_coords_tab<LDS, INTERP>(L, W, min(wcode<WIDE>(in.r, i), mi), min(wcode<WIDE>(in.g, i), mi),
-                                                     min(wcode<WIDE>(in.b, i), mi), bn);
-            o = px_quant(L, px_blend<LDS, INTERP>(L, W, c));
-        } else {
-            o = lut_px<LDS, INTERP>(L, W, wsample<WIDE>(in.r, i), wsample<WIDE>(in.g, i), wsample<WIDE>(in.b, i), bn);
+    for (int g = 0; g < RgbTile<WIDE>::PXT / 4; g++) {
+        PxC pc[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int i = g * 4 + p;
+            if constexpr (TAB) {
+                // codes above 2^depth-1 cannot occur in a valid plane; clamp so a stray one cannot index past the table
+                const unsigned mi = (unsigned)L.maxf;
+                pc[p] = px_coords_tab<LDS, INTERP>(L, W, min(wcode<WIDE>(in.r, i), mi), min(wcode<WIDE>(in.g, i), mi),
+                                                   min(wcode<WIDE>(in.b, i), mi), bn);
+            } else {
+                pc[p] = px_coords<LDS, INTERP>(L, W, wsample<WIDE>(in.r, i), wsample<WIDE>(in.g, i), wsample<WIDE>(in.b, i), bn);
+            }
         }
-        wput<WIDE>(out.g, i, o.g);
-        wput<WIDE>(out.b, i, o.b);
-        wput<WIDE>(out.r, i, o.r);
-        if ((i & 1) == 1) {
-            fence_words<4>(in.g); fence_words<4>(in.b); fence_words<4>(in.r);
-            fence_words<4>(out.g); fence_words<4>(out.b); fence_words<4>(out.r);
+        Rgb3 o[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = px_quant(L, px_blend<LDS, INTERP>(L, W, pc[p]));
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int i = g * 4 + p;
+            wput<WIDE>(out.g, i, o[p].g);
+            wput<WIDE>(out.b, i, o[p].b);
+            wput<WIDE>(out.r, i, o[p].r);
         }
+        fence_words<4>(in.g); fence_words<4>(in.b); fence_words<4>(in.r);
+        fence_words<4>(out.g); fence_words<4>(out.b); fence_words<4>(out.r);
     }
 }
 

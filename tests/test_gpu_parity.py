@@ -241,3 +241,34 @@ def test_tile_window_statistics(engine, cube_dir):
         else:
             assert st["global_tiles"] + st["misses"] < 0.5 * st["tiles"]
     engine.set_variant("auto")
+
+
+def test_distributed_lut_load_single_rank_rccl(orc, cube_dir):
+    """The RCCL path of `set_lut_distributed` (broadcast straight into the device lattice) with a
+    one-rank nccl group: everything bench.py --gpus N does except having peers."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from lut_renderer_amd.engine import LutEngine
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        lut = cube.read_cube(cube_dir / "log709_33.cube")
+        with LutEngine(0) as eng:
+            eng.set_lut_distributed(lut, src=0)
+            lat = eng.lattice_tensor()
+            assert lat.numel() == 34 ** 3 * 4 and lat.is_cuda
+            # padded layout: node (r,g,b) at ((r*34+g)*34+b)*4, last node replicated at index 33
+            host = lat.cpu().numpy().reshape(34, 34, 34, 4)
+            assert np.array_equal(host[:33, :33, :33, :3], lut.table)
+            assert np.array_equal(host[33, 33, 33, :3], lut.table[32, 32, 32])
+            src = frames.natural_yuv(256, 64, 10, 1, 1, k=1)
+            out = eng.apply_yuv(_to_dev(src, eng), pix_fmt="yuv420p10le")
+            k = orc.yuv_constants(din=10)
+            _assert_equal(_to_np(out, np.uint16),
+                          orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src), "rccl lut load")
+    finally:
+        dist.destroy_process_group()
