@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--unique", type=int, default=2, help="distinct synthetic frames tiled into the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stats", action="store_true", help="skip the extra LDS-window statistics pass (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--extra", action="store_true", help="also time the other distribution / mode (stderr only)")
     return ap.parse_args()
@@ -201,7 +202,7 @@ def main():
     wall, kern = time_steps(eng, pf, src, dst, args.fmt, args.interp, args.steps, args.warmup, world)
     kernel_name = eng.last_kernel
     tile_stats = None
-    if "tile" in kernel_name:                    # one extra, untimed pass with the window counters armed
+    if "tile" in kernel_name and not args.no_stats:   # one extra, untimed pass with the window counters armed
         eng.tile_stats(True)
         apply(eng, pf, src, dst, args.fmt, args.interp)
         tile_stats = eng.tile_stats(False)

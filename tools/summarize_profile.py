@@ -18,10 +18,14 @@ src = Path("gpurun_out") / f"prof_{tag}"
 dst = Path("profiles")
 dst.mkdir(exist_ok=True)
 summary = {"tag": tag}
-for f in glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")):
+for f in sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")))[-1:]:
     shutil.copy(f, dst / f"{rnd}_{tag}_kernel_stats.csv")
     rows = list(csv.DictReader(open(f)))
-    summary["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage")} for r in rows[:4]]
+    summary["kernel_stats"] = [{k: r[k][:120] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")}
+                               for r in rows[:3]]
+for f in sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_trace.csv")))[-1:]:
+    rows = [r for r in csv.DictReader(open(f)) if "lutr::k_" in r["Kernel_Name"]]
+    summary["dispatch_us"] = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1) for r in rows]
 counters = defaultdict(list)
 kernel = None
 for sub in ("fetch", "write", "sq", "tcc"):
