@@ -57,6 +57,10 @@ def parse_args():
     ap.add_argument("--no-stats", action="store_true", help="skip the extra LDS-window statistics pass (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--extra", action="store_true", help="also time the other distribution / mode (stderr only)")
+    ap.add_argument("--pipeline", default="hbm", choices=["hbm", "host"],
+                    help="host: also time BASELINE config 5 (frames in pinned host memory, overlapped copies); "
+                         "reported as `host_pipeline`, never as `value`")
+    ap.add_argument("--host-frames", type=int, default=256)
     return ap.parse_args()
 
 
@@ -233,6 +237,25 @@ def main():
                     f"{eng.tile_stats(False)}")
                 del s2
 
+    host_pipe = None
+    if args.pipeline == "host" and rank == 0 and pf.family == "yuv":
+        from lut_renderer_amd.stream import HostPipeline
+        pipe = HostPipeline(eng, args.fmt, w, h, batch=8, slots=3, interp=args.interp)
+        one = b"".join(np.ascontiguousarray(t[0].cpu().numpy()).tobytes() for t in src)
+        for sl in range(pipe.slots):                 # inputs pre-filled: the producer is not what is measured
+            pipe.host_in(sl)[:] = np.frombuffer(one * pipe.batch, dtype=np.uint8)
+        pipe.run(lambda b, m: m, lambda b, k: None, total_frames=24)        # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_done = pipe.run(lambda b, m: m, lambda b, k: None, total_frames=args.host_frames)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        gb = n_done * (pipe.fin.frame_bytes + pipe.fout.frame_bytes) / 1e9
+        host_pipe = {"frames": n_done, "fps": round(n_done / el, 1), "Mpixels_s": round(n_done * w * h / el / 1e6, 1),
+                     "pcie_GBps_each_way": round(gb / 2 / el, 1),
+                     "note": "frames in pinned host memory, 3-slot ring of 8-frame batches, H2D / kernel / D2H on "
+                             "separate streams; PCIe Gen5 x16-bound (63 GB/s per direction spec)"}
+        log(f"[host pipeline] {host_pipe}")
     if rank == 0:
         bpp_in = (3.0 if pf.family == "gbr" else 1.0 + 2.0 / (1 << (pf.csx + pf.csy))) * (1 if pf.depth <= 8 else 2)
         bpp = 2.0 * bpp_in                                        # in + out, same format
@@ -269,6 +292,8 @@ def main():
         }
         if extra:
             result["extra_Mpx_s"] = extra
+        if host_pipe:
+            result["host_pipeline"] = host_pipe
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(lut, pf, w, h, args.interp, args.dist, args.cpu_seconds)
         elif world > 1:

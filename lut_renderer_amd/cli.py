@@ -1,0 +1,108 @@
+"""Engine CLI with the process contract `TaskRunner._run_stage` expects from ffmpeg
+(/root/reference/src/lut_renderer/task_manager.py:134-190): started with Popen(stdout=PIPE,
+stderr=STDOUT, text=True), it prints one `Duration: HH:MM:SS.xx` line, then `time=HH:MM:SS.xx`
+progress lines (regexes at task_manager.py:14-15), exits 0 on success and non-zero with a message
+on error, and stops on SIGTERM (task_manager.py:38-44).
+
+It works on rawvideo files (planar frames back to back), i.e. the stage between a decoder and an
+encoder; the options are the reference's own LUT vocabulary (models.py:45-56):
+
+    python -m lut_renderer_amd.cli -i in.yuv -o out.yuv --size 3840x2160 --pix-fmt yuv420p10le \
+        --cube look.cube --interp tetrahedral --colorspace bt2020nc --color-range tv
+
+SURVEY.md 8f rank 1.  Frames stream through `stream.HostPipeline` (pinned ring, overlapped copies).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import signal
+import sys
+import time
+
+
+def _hms(seconds: float) -> str:
+    seconds = max(0.0, seconds)
+    h, rem = divmod(seconds, 3600)
+    m, s = divmod(rem, 60)
+    return f"{int(h):02d}:{int(m):02d}:{s:05.2f}"
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="lut_renderer_amd.cli", description=__doc__.split("\n\n")[0])
+    ap.add_argument("-i", "--input", required=True)
+    ap.add_argument("-o", "--output", required=True)
+    ap.add_argument("--size", required=True, help="WxH")
+    ap.add_argument("--pix-fmt", required=True)
+    ap.add_argument("--out-pix-fmt", default=None)
+    ap.add_argument("--cube", required=True)
+    ap.add_argument("--interp", default="tetrahedral")
+    ap.add_argument("--input-matrix", default="auto")
+    ap.add_argument("--output-tags", default="bt709")
+    ap.add_argument("--colorspace", default=None)
+    ap.add_argument("--color-range", default=None)
+    ap.add_argument("--fps", type=float, default=25.0)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("-y", action="store_true", help="overwrite the output (ffmpeg's -y)")
+    args = ap.parse_args(argv)
+
+    stop = {"flag": False}
+    signal.signal(signal.SIGTERM, lambda *_: stop.__setitem__("flag", True))
+    try:
+        w, h = (int(v) for v in args.size.lower().split("x"))
+        if os.path.exists(args.output) and not args.y:
+            raise FileExistsError(f"{args.output} exists (pass -y to overwrite)")
+        from .api import engine_call_for
+        from .cube import read_cube
+        from .engine import LutEngine
+        from .params import ProcessingParams, VideoInfo, infer_bit_depth
+        from .plan import resolve_lut_plan
+        from .stream import HostPipeline
+
+        params = ProcessingParams(lut_interp=args.interp, lut_input_matrix=args.input_matrix,
+                                  lut_output_tags=args.output_tags)
+        info = VideoInfo(width=w, height=h, pix_fmt=args.pix_fmt, bit_depth=infer_bit_depth(args.pix_fmt),
+                         colorspace=args.colorspace, color_range=args.color_range)
+        plan = resolve_lut_plan(params, args.cube, info)
+        kw = engine_call_for(plan, args.pix_fmt, args.out_pix_fmt)
+        eng = LutEngine(args.device)
+        eng.set_lut(read_cube(args.cube))
+        pix_fmt, out_fmt = kw.pop("pix_fmt"), kw.pop("out_pix_fmt")
+        pipe = HostPipeline(eng, pix_fmt, w, h, batch=args.batch, out_pix_fmt=out_fmt, **kw)
+        fb = pipe.fin.frame_bytes
+        total = os.path.getsize(args.input) // fb
+        if total == 0:
+            raise ValueError(f"{args.input}: no complete {w}x{h} {args.pix_fmt} frame ({fb} bytes each)")
+        print(f"Input #0, rawvideo, from '{args.input}':", flush=True)
+        print(f"  Duration: {_hms(total / args.fps)}, {total} frames, {w}x{h} {args.pix_fmt}", flush=True)
+        for note in plan.notes:
+            print(f"  {note}", flush=True)
+        t0 = time.time()
+        state = {"done": 0}
+        with open(args.input, "rb") as fi, open(args.output, "wb") as fo:
+            def fill(buf, max_frames):
+                got = fi.readinto(memoryview(buf)[: max_frames * fb])
+                return got // fb
+
+            def drain(buf, n):
+                fo.write(memoryview(buf))
+                state["done"] += n
+                el = max(time.time() - t0, 1e-9)
+                print(f"frame={state['done']:6d} fps={state['done'] / el:7.1f} time={_hms(state['done'] / args.fps)}",
+                      flush=True)
+
+            pipe.run(fill, drain, total_frames=total, stop=lambda: stop["flag"])
+        eng.close()
+        if stop["flag"]:
+            print("Exiting normally, received signal 15.", flush=True)
+            return 255
+        print(f"video: {state['done']} frames written to '{args.output}'", flush=True)
+        return 0
+    except Exception as exc:  # the caller only sees text + exit code (task_manager.py:105-112)
+        print(f"Error: {exc}", flush=True)
+        return 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -272,3 +272,29 @@ def test_distributed_lut_load_single_rank_rccl(orc, cube_dir):
                           orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src), "rccl lut load")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [2, 3, 17, 65, 128, 256])
+def test_lattice_sizes_min_to_max(engine, orc, n):
+    """LUT_3D_SIZE from the smallest (2) to FFmpeg's MAX_LEVEL (256): every kernel family, both modes.
+    (257^3 float4 nodes = 271 MB on the device; addresses beyond 2^24 need the integer index path.)"""
+    from lut_renderer_amd.cube import CubeLut
+    rng = np.random.default_rng(n)
+    tab = rng.uniform(0.0, 1.0, size=(n, n, n, 3)).astype(np.float32)
+    lut = CubeLut(n, np.ones(3, dtype=np.float32), tab)
+    engine.set_lut(lut)
+    src = frames.uniform_yuv(128, 36, 10, 1, 1, k=n)
+    rgb = frames.uniform_rgb(128, 36, 10, k=n)
+    rgb[0][0, :8] = 1023; rgb[1][0, :8] = 1023; rgb[2][0, :8] = 1023        # the last node exactly
+    rgb[0][1, :8] = 0; rgb[1][1, :8] = 1023; rgb[2][1, :8] = 0
+    k = orc.yuv_constants(din=10)
+    for variant in ("generic", "vec_global", "vec_lds"):
+        engine.set_variant(variant)
+        for mode in ("trilinear", "tetrahedral", "nearest"):
+            want = orc.apply_yuv(tab, lut.scale, mode, k, 10, 10, 10, 1, 1, src)
+            got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le", interp=mode)
+            _assert_equal(_to_np(got, np.uint16), want, f"N={n} {variant} {mode} yuv")
+            want = orc.apply_rgb(tab, lut.scale, 10, mode, rgb)
+            got = engine.apply_rgb(_to_dev(rgb, engine), depth=10, interp=mode)
+            _assert_equal(_to_np(got, np.uint16), want, f"N={n} {variant} {mode} rgb")
+    engine.set_variant("auto")
