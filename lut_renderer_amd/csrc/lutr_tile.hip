@@ -87,6 +87,15 @@ __device__ __forceinline__ void bnd_reset(Bnd &b)
 // to b96, which the LDS serves at 8 cycles per wave-instruction instead of 4; MI355X_MICROARCH.md).
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// bounds of the touched cells in sheared coordinates (r, g-r, b-r)
+__device__ __forceinline__ void bnd_update(Bnd &bn, float pr, float pg, float pb)
+{
+    const float hg = pg - pr, hb = pb - pr;
+    bn.rmin = fminf(bn.rmin, pr); bn.rmax = fmaxf(bn.rmax, pr);
+    bn.gmin = fminf(bn.gmin, hg); bn.gmax = fmaxf(bn.gmax, hg);
+    bn.bmin = fminf(bn.bmin, hb); bn.bmax = fmaxf(bn.bmax, hb);
+}
+
 template <bool LDS>
 __device__ __forceinline__ f4 tap(const float4 *__restrict__ lat, int a)
 {
@@ -146,12 +155,7 @@ template <bool LDS, int INTERP>
 __device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const Crd &cr, const Crd &cg, const Crd &cb, Bnd &bn)
 {
     const float pr = cr.p, pg = cg.p, pb = cb.p;
-    {   // bounds in sheared coordinates
-        const float hg = pg - pr, hb = pb - pr;
-        bn.rmin = fminf(bn.rmin, pr); bn.rmax = fmaxf(bn.rmax, pr);
-        bn.gmin = fminf(bn.gmin, hg); bn.gmax = fmaxf(bn.gmax, hg);
-        bn.bmin = fminf(bn.bmin, hb); bn.bmax = fmaxf(bn.bmax, hb);
-    }
+    bnd_update(bn, pr, pg, pb);
     PxC c;
     if constexpr (LDS) {
         // exact in fp32: every term is an integer well below 2^24 for a window of <= 4096 nodes
@@ -508,6 +512,48 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
     }
 }
 
+// Bounds-only pass: the cells a tile touches, without taps, blend or outputs (about a quarter of a full
+// pass).  Run on the first tile of a chunk, where the wave's window comes from somewhere else on the
+// frame and an optimistic full pass would almost surely be thrown away.  Does not consume `in`.
+template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, bool TAB>
+__device__ __forceinline__ void yuv_tile_bounds(const LutConsts &L, const YuvConsts &K, YuvTile<WIDE, CSX, CSY> &in, Bnd &bn)
+{
+    // consumes `in` like the full body (ordering fences), so the caller re-loads the tile afterwards
+    using T = YuvTile<WIDE, CSX, CSY>;
+#pragma unroll
+    for (int j = 0; j < T::NC; j++) {
+        float cbv = wsample<WIDE>(in.cb, j), crv = wsample<WIDE>(in.cr, j);
+        if constexpr (PRE) {
+            cbv = cfloor(tfma(K.pc, cbv, K.pcb), K.pre_max);
+            crv = cfloor(tfma(K.pc, crv, K.pcb), K.pre_max);
+        }
+        const float cbd = cbv - K.coff, crd = crv - K.coff;
+        const float rv = K.krv * crd, gv = tfma(K.kgu, cbd, K.kgv * crd), bu = K.kbu * cbd;
+#pragma unroll
+        for (int dy = 0; dy < T::BH; dy++) {
+#pragma unroll
+            for (int dx = 0; dx < T::BW; dx++) {
+                float yv = wsample<WIDE>(in.y[dy], j * T::BW + dx);
+                if constexpr (PRE) yv = cfloor(tfma(K.py, yv, K.pyb), K.pre_max);
+                const float yy = tfma(K.ky, yv, K.yb);
+                if constexpr (TAB) {
+                    const unsigned mi = (unsigned)K.max_l;
+                    bnd_update(bn, crd_table(min((unsigned)(yy + rv), mi)).p, crd_table(min((unsigned)(yy + gv), mi)).p,
+                               crd_table(min((unsigned)(yy + bu), mi)).p);
+                } else {
+                    bnd_update(bn, crd_compute<INTERP>(L, cfloor(yy + rv, K.max_l), L.sc[0]).p,
+                               crd_compute<INTERP>(L, cfloor(yy + gv, K.max_l), L.sc[1]).p,
+                               crd_compute<INTERP>(L, cfloor(yy + bu, K.max_l), L.sc[2]).p);
+                }
+            }
+        }
+        fence_words<T::YW * T::BH>(&in.y[0][0]);
+        fence_words<T::CW>(in.cb);
+        fence_words<T::CW>(in.cr);
+        asm volatile("" : "+v"(bn.rmin), "+v"(bn.rmax), "+v"(bn.gmin), "+v"(bn.gmax), "+v"(bn.bmin), "+v"(bn.bmax));
+    }
+}
+
 // 4 waves per SIMD: the kernel needs 127 VGPRs once the input tile is consumed in place (keeping
 // a pristine copy for the rare miss pass cost 41 registers).  5 waves (96 VGPRs) spills into
 // the hot loop and is slower (232 vs 284 Gpx/s on UHD yuv420p10le tetrahedral).
@@ -579,8 +625,11 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     T nxt;
     load_tile(nxt, fr, sx, ry);
+    bool nxt_fresh = true;                                    // the tile in `nxt` starts a chunk
     for (bool more = true; more;) {
         T in = nxt;
+        const bool fresh = nxt_fresh;
+        nxt_fresh = false;
         const int cfr = fr, csx = sx, cry = ry;
         // Next tile: the one below in this chunk, else the first tile of a newly claimed chunk.  Its loads
         // are issued NOW, before this tile's stores: vmcnt retires in order, so loads issued after the
@@ -588,11 +637,21 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
         // simply fetched again, so every path has the same number of memory operations in flight and
         // hipcc can wait with a counted vmcnt instead of vmcnt(0).
         if (--rem > 0) ry++;
-        else more = claim_chunk(TG, lane, fr, sx, ry, rem);
+        else { more = claim_chunk(TG, lane, fr, sx, ry, rem); nxt_fresh = true; }
         load_tile(nxt, fr, sx, ry);
 
         T out;
         Bnd bn;
+        if (fresh) {        // new place on the frame: size the window from a cheap bounds pass first
+            bnd_reset(bn);
+            yuv_tile_bounds<WIDE, CSX, CSY, INTERP, PRE, TAB>(L, K, in, bn);
+            if (!lds_mode || !win_holds(W, bn)) {
+                lds_mode = win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane);
+                if (lds_mode) ws.n[3]++;
+            }
+            load_tile(in, cfr, csx, cry);              // the bounds pass consumed the tile; L2 still has it
+            __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0) here keeps the waits of the main path counted
+        }
         for (;;) {
             bnd_reset(bn);
             if (lds_mode) {
@@ -693,6 +752,27 @@ __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, 
 }
 
 template <int WIDE, int INTERP, bool TAB>
+__device__ __forceinline__ void rgb_tile_bounds(const LutConsts &L, RgbTile<WIDE> &in, Bnd &bn)
+{
+#pragma unroll
+    for (int i = 0; i < RgbTile<WIDE>::PXT; i++) {
+        if constexpr (TAB) {
+            const unsigned mi = (unsigned)L.maxf;
+            bnd_update(bn, crd_table(min(wcode<WIDE>(in.r, i), mi)).p, crd_table(min(wcode<WIDE>(in.g, i), mi)).p,
+                       crd_table(min(wcode<WIDE>(in.b, i), mi)).p);
+        } else {
+            bnd_update(bn, crd_compute<INTERP>(L, wsample<WIDE>(in.r, i), L.sc[0]).p,
+                       crd_compute<INTERP>(L, wsample<WIDE>(in.g, i), L.sc[1]).p,
+                       crd_compute<INTERP>(L, wsample<WIDE>(in.b, i), L.sc[2]).p);
+        }
+        if ((i & 3) == 3) {
+            fence_words<4>(in.g); fence_words<4>(in.b); fence_words<4>(in.r);
+            asm volatile("" : "+v"(bn.rmin), "+v"(bn.rmax), "+v"(bn.gmin), "+v"(bn.gmax), "+v"(bn.bmin), "+v"(bn.bmax));
+        }
+    }
+}
+
+template <int WIDE, int INTERP, bool TAB>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
 void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
 {
@@ -725,15 +805,28 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
     WaveStats ws;
     T nxt;
     load_tile(nxt, fr, sx, ry);
+    bool nxt_fresh = true;
     for (bool more = true; more;) {
         T in = nxt;
+        const bool fresh = nxt_fresh;
+        nxt_fresh = false;
         const int cfr = fr, csx = sx, cry = ry;
         if (--rem > 0) ry++;                    // next tile of the chunk, or a new chunk (see k_yuv_tile)
-        else more = claim_chunk(TG, lane, fr, sx, ry, rem);
+        else { more = claim_chunk(TG, lane, fr, sx, ry, rem); nxt_fresh = true; }
         load_tile(nxt, fr, sx, ry);
 
         T out;
         Bnd bn;
+        if (fresh) {
+            bnd_reset(bn);
+            rgb_tile_bounds<WIDE, INTERP, TAB>(L, in, bn);
+            if (!lds_mode || !win_holds(W, bn)) {
+                lds_mode = win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane);
+                if (lds_mode) ws.n[3]++;
+            }
+            load_tile(in, cfr, csx, cry);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+        }
         for (;;) {
             bnd_reset(bn);
             if (lds_mode) {
