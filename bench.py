@@ -210,7 +210,6 @@ def main():
         eng.tile_stats(True)
         apply(eng, pf, src, dst, args.fmt, args.interp)
         tile_stats = eng.tile_stats(False)
-        tile_stats.pop("clock", None)
         if rank == 0:
             log(f"[tile stats] {tile_stats}")
     t = torch.tensor([wall, kern, float(px_rank)], dtype=torch.float64, device=eng.device)

@@ -158,10 +158,11 @@ int lutr_apply_yuv(lutr_ctx *ctx, const lutr_yuv_params *p, int interp, int w, i
 int lutr_ctx_set_variant(lutr_ctx *ctx, int variant);
 /* name of the kernel variant the last apply call launched ("" before the first) */
 const char *lutr_ctx_last_kernel(lutr_ctx *ctx);
-/* LDS-window statistics of the tile kernels.  Reads the counters accumulated since the last
- * call into out[4] = {tiles, optimistic passes that missed, tiles done by the global-gather
- * body, windows staged} (out may be NULL), then enables (and zeroes) or disables collection. */
-int lutr_ctx_tile_stats(lutr_ctx *ctx, int enable, uint64_t out[4]);
+/* Statistics of the LDS-window tile kernels, accumulated since the previous call.  out[8] (may be
+ * NULL) = { tiles, full passes that missed the window, tiles done by the global-gather body, windows
+ * staged, shader clock in MHz, longest wave lifetime in us, summed wave lifetimes in us, 0 }.
+ * Then collection is enabled (and zeroed) or disabled. */
+int lutr_ctx_tile_stats(lutr_ctx *ctx, int enable, uint64_t out[8]);
 /* the constant block the YUV kernels use, for cross-checking against the oracle: 32 floats */
 int lutr_yuv_constants(const lutr_yuv_params *p, float out[32]);
 

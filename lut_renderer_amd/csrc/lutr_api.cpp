@@ -268,19 +268,20 @@ int lutr_ctx_set_variant(lutr_ctx *c, int variant)
 
 const char *lutr_ctx_last_kernel(lutr_ctx *c) { return c ? c->last_kernel.c_str() : ""; }
 
-int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[4])
+int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[8])
 {
     if (!c) { set_error("null context"); return LUTR_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     if (out) {
-        for (int i = 0; i < 4; i++) out[i] = 0;
+        for (int i = 0; i < 8; i++) out[i] = 0;
         if (c->stats) {
             unsigned h[12];
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
             for (int i = 0; i < 4; i++) out[i] = h[i];
-            if (h[5]) set_error("clock %.3f GHz (shader cycles %u / 100MHz ticks %u, >>8) segs issue-prefetch %u wait-input %u body %u stores %u; wave life max %.1f us, sum/64 %u ticks",
-                                0.1 * h[4] / h[5], h[4], h[5], h[6], h[7], h[8], h[9], h[10] / 100.0, h[11]);
+            out[4] = h[5] ? (uint64_t)(100.0 * h[4] / h[5] + 0.5) : 0;          // shader clock, MHz (memtime / 100 MHz realtime)
+            out[5] = h[10] / 100;                                                 // longest wave lifetime, us
+            out[6] = (uint64_t)h[11] * 64 / 100;                   // summed wave lifetimes, us
         }
     }
     if (enable && !c->stats) {

@@ -179,13 +179,10 @@ class LutEngine:
 
     def tile_stats(self, enable: bool = True) -> dict:
         """Counters of the LDS-window kernels since the previous call; (re)arms collection."""
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         _native.check(self._lib.lutr_ctx_tile_stats(self._ctx, int(enable), out))
-        res = {"tiles": out[0], "misses": out[1], "global_tiles": out[2], "staged": out[3]}
-        msg = self._lib.lutr_last_error().decode()
-        if msg.startswith("clock "):
-            res["clock"] = msg
-        return res
+        return {"tiles": out[0], "misses": out[1], "global_tiles": out[2], "staged": out[3],
+                "clock_mhz": out[4], "max_wave_us": out[5], "sum_wave_us": out[6]}
 
     def sync(self) -> None:
         _native.check(self._lib.lutr_ctx_sync(self._ctx))
