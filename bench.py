@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (SURVEY 8d: >= 64)")
     ap.add_argument("--size", default="uhd", choices=sorted(SIZES))
     ap.add_argument("--fmt", default="yuv420p10le")
     ap.add_argument("--interp", default="tetrahedral")

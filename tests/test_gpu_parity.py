@@ -298,3 +298,52 @@ def test_lattice_sizes_min_to_max(engine, orc, n):
             got = engine.apply_rgb(_to_dev(rgb, engine), depth=10, interp=mode)
             _assert_equal(_to_np(got, np.uint16), want, f"N={n} {variant} {mode} rgb")
     engine.set_variant("auto")
+
+
+def test_padded_strides_in_place_and_bottom_up(engine, orc, cube_dir):
+    """Layouts FFmpeg frames really have: linesize > width (padding), in-place filtering (lut3d writes into a
+    writable input frame) and negative linesize (bottom-up), which must fall back to the generic kernel."""
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    w, h = 256, 40
+    src = frames.natural_yuv(w, h, 10, 1, 1, k=21)
+    k = orc.yuv_constants(din=10)
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src)
+
+    def padded(p, pad):
+        big = torch.full((p.shape[0], p.shape[1] + pad), -1, dtype=torch.int16, device=engine.device)
+        big[:, : p.shape[1]] = torch.from_numpy(p.view(np.int16)).to(engine.device)
+        return big[:, : p.shape[1]]                      # a view with row stride = width + pad
+
+    for variant in ("generic", "vec_global", "vec_lds"):
+        engine.set_variant(variant)
+        s = [padded(src[0], 64), padded(src[1], 32), padded(src[2], 32)]
+        d = [padded(np.zeros_like(src[0]), 128), padded(np.zeros_like(src[1]), 64), padded(np.zeros_like(src[2]), 64)]
+        engine.apply_yuv(s, d, pix_fmt="yuv420p10le")
+        _assert_equal(_to_np([t.contiguous() for t in d], np.uint16), want, f"padded strides {variant}")
+        pad_ok = bool((d[0].as_strided((h, 128), (w + 128, 1), w) == -1).all())
+        assert int(d[0].storage_offset()) == 0 and pad_ok, "padding bytes beyond the row must stay untouched"
+        # in place: dst planes are the src planes
+        s2 = _to_dev(src, engine)
+        engine.apply_yuv(s2, s2, pix_fmt="yuv420p10le")
+        _assert_equal(_to_np(s2, np.uint16), want, f"in place {variant}")
+    engine.set_variant("auto")
+    # bottom-up source (negative row stride): torch cannot express it, so go through the C-ABI directly
+    import ctypes as C
+    from lut_renderer_amd import _native
+    lib = _native.load()
+    s3 = _to_dev(src, engine)
+    d3 = [torch.zeros_like(t) for t in s3]
+    sp, dp = _native.Planes(), _native.Planes()
+    for i, (a, b) in enumerate(zip(s3, d3)):
+        rows, rb = a.shape[0], a.shape[1] * 2
+        sp.data[i] = a.data_ptr() + (rows - 1) * rb
+        sp.stride[i] = -rb
+        dp.data[i] = b.data_ptr() + (rows - 1) * rb
+        dp.stride[i] = -rb
+    p = _native.YuvParams(_native.fmt_code(10, 1, 1), _native.fmt_code(10, 1, 1), 10, 0, 0, 0, 0, 0)
+    flipped = [np.ascontiguousarray(x[::-1]) for x in src]
+    want_f = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, flipped)
+    _native.check(lib.lutr_apply_yuv(engine._ctx, C.byref(p), 2, w, h, 1, C.byref(sp), C.byref(dp), 0, h))
+    torch.cuda.synchronize()
+    assert engine.last_kernel == "k_yuv_generic"
+    _assert_equal([x[::-1] for x in _to_np(d3, np.uint16)], want_f, "bottom-up")
