@@ -110,6 +110,33 @@ typedef struct lutr_planes {
     int64_t   frame_stride[3];
 } lutr_planes;
 
+/* Packed (interleaved) RGB formats lut3d accepts: bits per component (8|16, 16 = little-endian
+ * uint16), components per pixel (3|4) and the component index of R, G, B inside a pixel; the
+ * remaining slot of a 4-component format (alpha or padding) is copied from source to destination. */
+#define LUTR_PACKED(bits, ncomp, ro, go, bo) ((bits) | ((ncomp) << 8) | ((ro) << 12) | ((go) << 16) | ((bo) << 20))
+#define LUTR_PACKED_BITS(f)  ((f) & 0xff)
+#define LUTR_PACKED_NCOMP(f) (((f) >> 8) & 0xf)
+#define LUTR_PACKED_RO(f)    (((f) >> 12) & 0xf)
+#define LUTR_PACKED_GO(f)    (((f) >> 16) & 0xf)
+#define LUTR_PACKED_BO(f)    (((f) >> 20) & 0xf)
+#define LUTR_PK_RGB24    LUTR_PACKED(8, 3, 0, 1, 2)
+#define LUTR_PK_BGR24    LUTR_PACKED(8, 3, 2, 1, 0)
+#define LUTR_PK_RGBA     LUTR_PACKED(8, 4, 0, 1, 2)   /* also rgb0 */
+#define LUTR_PK_BGRA     LUTR_PACKED(8, 4, 2, 1, 0)   /* also bgr0 */
+#define LUTR_PK_ARGB     LUTR_PACKED(8, 4, 1, 2, 3)   /* also 0rgb */
+#define LUTR_PK_ABGR     LUTR_PACKED(8, 4, 3, 2, 1)   /* also 0bgr */
+#define LUTR_PK_RGB48LE  LUTR_PACKED(16, 3, 0, 1, 2)
+#define LUTR_PK_BGR48LE  LUTR_PACKED(16, 3, 2, 1, 0)
+#define LUTR_PK_RGBA64LE LUTR_PACKED(16, 4, 0, 1, 2)
+#define LUTR_PK_BGRA64LE LUTR_PACKED(16, 4, 2, 1, 0)
+
+/* one interleaved image, or a batch of equally laid out ones */
+typedef struct lutr_packed {
+    void     *data;
+    ptrdiff_t stride;          /* bytes between rows */
+    int64_t   frame_stride;    /* bytes between frames of a batch (ignored when nframes == 1) */
+} lutr_packed;
+
 typedef struct lutr_ctx lutr_ctx;
 
 const char *lutr_version(void);
@@ -146,6 +173,11 @@ size_t lutr_lattice_bytes(int n);
  * luma rows [row0, row0+rows) of each of nframes frames. */
 int lutr_apply_planar_rgb(lutr_ctx *ctx, int depth, int interp, int w, int h, int nframes,
                           const lutr_planes *src, const lutr_planes *dst, int row0, int rows);
+
+/* lut3d on packed RGB (`pfmt` = one of LUTR_PK_* / LUTR_PACKED(...)); M = 255 or 65535.  16-bit
+ * formats need 2-byte aligned rows.  src == dst (in place) is allowed. */
+int lutr_apply_packed_rgb(lutr_ctx *ctx, int pfmt, int interp, int w, int h, int nframes,
+                          const lutr_packed *src, const lutr_packed *dst, int row0, int rows);
 
 /* fused YUV -> RGB -> lut3d -> RGB -> YUV; row0 and rows must be multiples of the
  * chroma block height (2 for 4:2:0) unless row0+rows == h. */

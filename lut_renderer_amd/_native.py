@@ -26,7 +26,7 @@ SYMBOLS = (
     "lutr_cube_parse", "lutr_cube_free",
     "lutr_ctx_create", "lutr_ctx_destroy", "lutr_ctx_set_stream", "lutr_ctx_sync",
     "lutr_ctx_set_lut", "lutr_ctx_lut_alloc", "lutr_ctx_lut_device", "lutr_lattice_bytes",
-    "lutr_apply_planar_rgb", "lutr_apply_yuv",
+    "lutr_apply_planar_rgb", "lutr_apply_packed_rgb", "lutr_apply_yuv",
     "lutr_ctx_set_variant", "lutr_ctx_last_kernel", "lutr_ctx_tile_stats", "lutr_yuv_constants",
 )
 
@@ -45,6 +45,26 @@ class YuvParams(C.Structure):
 class Planes(C.Structure):
     """struct lutr_planes"""
     _fields_ = [("data", C.c_void_p * 3), ("stride", C.c_ssize_t * 3), ("frame_stride", C.c_int64 * 3)]
+
+
+class Packed(C.Structure):
+    """struct lutr_packed"""
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_ssize_t), ("frame_stride", C.c_int64)]
+
+
+def packed_code(bits: int, ncomp: int, ro: int, go: int, bo: int) -> int:
+    """LUTR_PACKED(bits, ncomp, ro, go, bo)"""
+    return bits | (ncomp << 8) | (ro << 12) | (go << 16) | (bo << 20)
+
+
+#: FFmpeg names of the packed RGB formats lut3d takes -> (bits, components, R, G, B component index)
+PACKED_FORMATS = {
+    "rgb24": (8, 3, 0, 1, 2), "bgr24": (8, 3, 2, 1, 0),
+    "rgba": (8, 4, 0, 1, 2), "rgb0": (8, 4, 0, 1, 2), "bgra": (8, 4, 2, 1, 0), "bgr0": (8, 4, 2, 1, 0),
+    "argb": (8, 4, 1, 2, 3), "0rgb": (8, 4, 1, 2, 3), "abgr": (8, 4, 3, 2, 1), "0bgr": (8, 4, 3, 2, 1),
+    "rgb48le": (16, 3, 0, 1, 2), "bgr48le": (16, 3, 2, 1, 0),
+    "rgba64le": (16, 4, 0, 1, 2), "bgra64le": (16, 4, 2, 1, 0),
+}
 
 
 class LutrError(RuntimeError):
@@ -85,6 +105,7 @@ def load() -> C.CDLL:
     lib.lutr_lattice_bytes.argtypes = [ci]
     lib.lutr_lattice_bytes.restype = C.c_size_t
     lib.lutr_apply_planar_rgb.argtypes = [vp, ci, ci, ci, ci, ci, C.POINTER(Planes), C.POINTER(Planes), ci, ci]
+    lib.lutr_apply_packed_rgb.argtypes = [vp, ci, ci, ci, ci, ci, C.POINTER(Packed), C.POINTER(Packed), ci, ci]
     lib.lutr_apply_yuv.argtypes = [vp, C.POINTER(YuvParams), ci, ci, ci, ci, C.POINTER(Planes), C.POINTER(Planes),
                                    ci, ci]
     lib.lutr_ctx_set_variant.argtypes = [vp, ci]

@@ -363,8 +363,8 @@ int lutr_ctx_lut_device(lutr_ctx *c, void **dptr, size_t *bytes)
     return LUTR_OK;
 }
 
-static int check_common(lutr_ctx *c, int interp, int w, int h, int nframes, const lutr_planes *src,
-                        const lutr_planes *dst, int row0, int rows)
+static int check_common(lutr_ctx *c, int interp, int w, int h, int nframes, const void *src,
+                        const void *dst, int row0, int rows)
 {
     if (!c || !src || !dst) { set_error("null argument"); return LUTR_EINVAL; }
     if (!c->lat) { set_error("no lattice set on this context (call lutr_ctx_set_lut first)"); return LUTR_EINVAL; }
@@ -428,6 +428,37 @@ int lutr_apply_planar_rgb(lutr_ctx *c, int depth, int interp, int w, int h, int 
     fill_lut(&L, c, depth);
     fill_planes(&P, src, dst);
     return finish_launch(c, launch_rgb(c->stream, c->variant, L, P, G, depth, interp, c->stats, c->queue));
+}
+
+int lutr_apply_packed_rgb(lutr_ctx *c, int pfmt, int interp, int w, int h, int nframes,
+                          const lutr_packed *src, const lutr_packed *dst, int row0, int rows)
+{
+    int rc = check_common(c, interp, w, h, nframes, src, dst, row0, rows);
+    if (rc) return rc;
+    const int bits = LUTR_PACKED_BITS(pfmt), nc = LUTR_PACKED_NCOMP(pfmt);
+    const int ro = LUTR_PACKED_RO(pfmt), go = LUTR_PACKED_GO(pfmt), bo = LUTR_PACKED_BO(pfmt);
+    if ((bits != 8 && bits != 16) || (nc != 3 && nc != 4) || (pfmt >> 24) || ro >= nc || go >= nc || bo >= nc ||
+        ro == go || go == bo || ro == bo) {
+        set_error("unsupported packed format 0x%x", pfmt);
+        return LUTR_EINVAL;
+    }
+    if (w == 0 || rows == 0 || nframes == 0) return LUTR_OK;
+    if (!src->data || !dst->data) { set_error("null image"); return LUTR_EINVAL; }
+    const int wide = bits == 16;
+    if (wide && (((uintptr_t)src->data | (uintptr_t)dst->data | (uintptr_t)src->stride | (uintptr_t)dst->stride |
+                  (nframes > 1 ? (uintptr_t)src->frame_stride | (uintptr_t)dst->frame_stride : 0)) & 1)) {
+        set_error("16-bit packed formats need 2-byte aligned rows");
+        return LUTR_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    LutConsts L; FrameGeom G{w, h, row0, rows, nframes};
+    fill_lut(&L, c, bits);
+    PackedSet P;
+    P.s = (const uint8_t *)src->data; P.d = (uint8_t *)dst->data;
+    P.ss = src->stride; P.ds = dst->stride;
+    P.sfs = src->frame_stride; P.dfs = dst->frame_stride;
+    P.ro = ro; P.go = go; P.bo = bo; P.ao = nc == 4 ? 6 - ro - go - bo : 3;
+    return finish_launch(c, launch_packed(c->stream, c->variant, L, P, G, wide, nc, interp));
 }
 
 int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int h, int nframes,

@@ -43,6 +43,14 @@ struct PlaneSet {
     long long sfs[3], dfs[3];        // frame strides, bytes
 };
 
+// one interleaved image (or batch): component offsets in units of one component
+struct PackedSet {
+    const uint8_t *s;
+    uint8_t       *d;
+    long long ss, ds, sfs, dfs;      // row / frame strides, bytes
+    int ro, go, bo, ao;              // ao = the fourth slot of 4-component formats (alpha or padding)
+};
+
 struct FrameGeom {
     int w, h, row0, rows, nframes;
 };
@@ -56,6 +64,10 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
 const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const YuvConsts &K,
                        const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy,
                        int interp, unsigned *stats, unsigned *queue);
+
+// packed RGB (lutr_packed.hip)
+const char *launch_packed(hipStream_t st, int variant, const LutConsts &L, const PackedSet &P, const FrameGeom &G,
+                          int wide, int ncomp, int interp);
 
 // persistent LDS-window kernels (lutr_tile.hip); layout already checked by launch_rgb/launch_yuv
 const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G,

@@ -209,6 +209,40 @@ class LutEngine:
             self._ctx, depth, _native.INTERP[interp], w, h, nf, C.byref(s), C.byref(d), row0, rows))
         return dst
 
+    def apply_packed(self, src: torch.Tensor, dst: Optional[torch.Tensor] = None, *, pix_fmt: str,
+                     interp: str = "tetrahedral", row0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
+        """lut3d on packed RGB: `src` is [H,W,C] or [F,H,W,C] (C = 3 or 4, uint8, or int16/uint16 for the
+        48/64-bit formats), `pix_fmt` an FFmpeg name from `_native.PACKED_FORMATS`.  The fourth component
+        is carried over.  `dst` may be `src` (in place)."""
+        if pix_fmt not in _native.PACKED_FORMATS:
+            raise ValueError(f"unsupported packed pixel format '{pix_fmt}'")
+        bits, nc, ro, go, bo = _native.PACKED_FORMATS[pix_fmt]
+        if dst is None:
+            dst = torch.empty_like(src)
+        descs = []
+        for t in (src, dst):
+            if not isinstance(t, torch.Tensor) or t.device != self.device:
+                raise ValueError("packed images must be torch tensors resident on the engine's GPU")
+            if t.dim() not in (3, 4) or t.shape[-1] != nc or t.element_size() * 8 != bits:
+                raise ValueError(f"'{pix_fmt}' takes [H,W,{nc}] or [F,H,W,{nc}] tensors of {bits}-bit elements")
+            if t.stride(-1) != 1 or t.stride(-2) != nc:
+                raise ValueError("pixels must be dense along the row")
+            st = _native.Packed()
+            st.data = t.data_ptr()
+            st.stride = t.stride(-3) * t.element_size()
+            st.frame_stride = t.stride(0) * t.element_size() if t.dim() == 4 else 0
+            descs.append(st)
+        if src.shape != dst.shape:
+            raise ValueError("src and dst shapes differ")
+        h, w = src.shape[-3], src.shape[-2]
+        nf = src.shape[0] if src.dim() == 4 else 1
+        rows = h - row0 if rows is None else rows
+        self._bind_stream()
+        _native.check(self._lib.lutr_apply_packed_rgb(
+            self._ctx, _native.packed_code(bits, nc, ro, go, bo), _native.INTERP[interp], w, h, nf,
+            C.byref(descs[0]), C.byref(descs[1]), row0, rows))
+        return dst
+
     def apply_yuv(self, src: Sequence[torch.Tensor], dst: Optional[Sequence[torch.Tensor]] = None, *,
                   pix_fmt: str, interp: str = "tetrahedral", matrix_in: str = "bt709",
                   matrix_out: Optional[str] = None, range_src: str = "tv", range_in: Optional[str] = None,

@@ -133,6 +133,30 @@ def apply_rgb(table, scale, depth: int, interp: str, planes, nthreads: int = 1):
     return dst
 
 
+#: packed RGB formats of FFmpeg's lut3d: name -> (bits, components, index of R, G, B);
+#: rgba_map semantics of libavfilter/drawutils ff_fill_rgba_map [FFmpeg-recall]
+PACKED = {
+    "rgb24": (8, 3, 0, 1, 2), "bgr24": (8, 3, 2, 1, 0),
+    "rgba": (8, 4, 0, 1, 2), "rgb0": (8, 4, 0, 1, 2), "bgra": (8, 4, 2, 1, 0), "bgr0": (8, 4, 2, 1, 0),
+    "argb": (8, 4, 1, 2, 3), "0rgb": (8, 4, 1, 2, 3), "abgr": (8, 4, 3, 2, 1), "0bgr": (8, 4, 3, 2, 1),
+    "rgb48le": (16, 3, 0, 1, 2), "bgr48le": (16, 3, 2, 1, 0),
+    "rgba64le": (16, 4, 0, 1, 2), "bgra64le": (16, 4, 2, 1, 0),
+}
+
+
+def apply_packed(table, scale, pix_fmt: str, interp: str, img, nthreads: int = 1):
+    """lut3d on one packed image [H,W,C] (uint8 / uint16): the same per-pixel arithmetic as the
+    planar path at depth 8 / 16 (A.3: M = 255 / 65535), components addressed through the format's
+    rgba map; the fourth component is copied (vf_lut3d.c `dst[x + a] = src[x + a]`)."""
+    bits, nc, ro, go, bo = PACKED[pix_fmt]
+    img = np.ascontiguousarray(img)
+    assert img.ndim == 3 and img.shape[2] == nc and img.dtype.itemsize * 8 == bits
+    g, b, r = apply_rgb(table, scale, bits, interp, (img[..., go], img[..., bo], img[..., ro]), nthreads)
+    out = img.copy()
+    out[..., ro], out[..., go], out[..., bo] = r, g, b
+    return out
+
+
 def yuv_constants(matrix_in="bt709", range_in="tv", matrix_out=None, range_out="tv",
                   din=8, dl=None, dout=None, chroma_n=4, prologue=False) -> YuvConsts:
     k = YuvConsts()

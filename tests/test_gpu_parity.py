@@ -347,3 +347,54 @@ def test_padded_strides_in_place_and_bottom_up(engine, orc, cube_dir):
     torch.cuda.synchronize()
     assert engine.last_kernel == "k_yuv_generic"
     _assert_equal([x[::-1] for x in _to_np(d3, np.uint16)], want_f, "bottom-up")
+
+
+@pytest.mark.parametrize("pix_fmt", ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr",
+                                     "rgb48le", "bgr48le", "rgba64le", "bgra64le"])
+def test_packed_rgb_parity(engine, orc, cube_dir, pix_fmt):
+    """the interleaved formats lut3d takes, vector and scalar kernels, every mode."""
+    bits, nc = orc.PACKED[pix_fmt][:2]
+    for lutname in ("log709_33.cube", "domain_2.cube"):
+        lut = _load(engine, cube_dir, lutname)
+        for (w, h) in ((128, 20), (37, 9)):                      # 37 wide -> scalar kernel
+            rng = np.random.default_rng(0xC0BE + w)
+            img = rng.integers(0, 1 << bits, size=(h, w, nc), dtype=np.uint16 if bits == 16 else np.uint8)
+            if w == 128:                                         # smooth half: neighbouring cells, all six tetrahedra
+                ramp = (np.add.outer(np.arange(h), np.arange(w)) * ((1 << bits) - 1) // (h + w)).astype(img.dtype)
+                img[:, : w // 2, :3] = ramp[:, : w // 2, None] ^ rng.integers(0, 8, size=(h, w // 2, 3), dtype=img.dtype)
+            dev = torch.from_numpy(img.view(np.int16) if bits == 16 else img).to(engine.device)
+            for variant in ("auto", "generic"):
+                engine.set_variant(variant)
+                for mode in (MODES5 if variant == "generic" or w == 37 else MODES3):
+                    want = orc.apply_packed(lut.table, lut.scale, pix_fmt, mode, img)
+                    got = engine.apply_packed(dev, pix_fmt=pix_fmt, interp=mode).cpu().numpy()
+                    got = got.view(np.uint16) if bits == 16 else got
+                    _assert_equal([got], [want], f"packed {pix_fmt} {variant} {mode} {w}x{h} {lutname}")
+                    expect = "k_packed_vec" if (variant == "auto" and w == 128 and mode in MODES3) else "k_packed_generic"
+                    assert engine.last_kernel.startswith(expect), engine.last_kernel
+    engine.set_variant("auto")
+
+
+def test_packed_rgb_batches_shards_in_place_and_padding(engine, orc, cube_dir):
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    rng = np.random.default_rng(7)
+    f, h, w = 3, 24, 64
+    img = rng.integers(0, 256, size=(f, h, w, 4), dtype=np.uint8)
+    want = np.stack([orc.apply_packed(lut.table, lut.scale, "bgra", "tetrahedral", img[i]) for i in range(f)])
+    # padded rows: a [F,H,W+8,4] buffer viewed at W
+    pad = torch.zeros((f, h, w + 8, 4), dtype=torch.uint8, device=engine.device)
+    view = pad[:, :, :w, :]
+    view.copy_(torch.from_numpy(img))
+    out = torch.full_like(pad, 0x55)
+    engine.apply_packed(view, out[:, :, :w, :], pix_fmt="bgra")
+    assert np.array_equal(out[:, :, :w, :].cpu().numpy(), want)
+    assert (out[:, :, w:, :] == 0x55).all()                      # padding untouched
+    # two row shards, in place
+    engine.apply_packed(view, view, pix_fmt="bgra", row0=0, rows=10)
+    engine.apply_packed(view, view, pix_fmt="bgra", row0=10, rows=14)
+    assert np.array_equal(view.cpu().numpy(), want)
+    # wrong element size / unknown name fail loudly
+    with pytest.raises(ValueError):
+        engine.apply_packed(view, pix_fmt="rgb48le")
+    with pytest.raises(ValueError):
+        engine.apply_packed(view, pix_fmt="rgb565")

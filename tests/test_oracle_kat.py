@@ -214,3 +214,23 @@ def test_prologue_full_to_limited(orc):
     k10 = orc.yuv_constants("bt709", "tv", "bt709", "tv", 10, 8, 8, 4, prologue=True)
     assert int(np.floor(f(k10.py) * f(1023) + f(k10.pyb))) == 235
     assert int(np.floor(f(k10.pc) * f(512) + f(k10.pcb))) == 128
+
+
+@pytest.mark.parametrize("pix_fmt", ["rgb24", "bgra", "argb", "0bgr", "bgr48le", "rgba64le"])
+def test_packed_oracle_is_the_pixel_function_through_the_rgba_map(orc, pix_fmt):
+    """Packed formats: same arithmetic as planar at depth 8 / 16, components picked by the
+    format's rgba map, fourth component copied."""
+    bits, nc, ro, go, bo = orc.PACKED[pix_fmt]
+    rng = np.random.default_rng(11)
+    table = rng.random((5, 5, 5, 3), dtype=np.float32)
+    scale = np.ones(3, np.float32)
+    img = rng.integers(0, 1 << bits, size=(3, 7, nc), dtype=np.uint16 if bits == 16 else np.uint8)
+    for mode in ("nearest", "trilinear", "tetrahedral", "pyramid", "prism"):
+        out = orc.apply_packed(table, scale, pix_fmt, mode, img)
+        for y, x in itertools.product(range(3), range(7)):
+            px = img[y, x]
+            r, g, b = orc.apply_pixel(table, scale, bits, mode, (px[ro], px[go], px[bo]))
+            assert (out[y, x, ro], out[y, x, go], out[y, x, bo]) == (r, g, b)
+            if nc == 4:
+                ao = 6 - ro - go - bo
+                assert out[y, x, ao] == px[ao]
