@@ -85,6 +85,8 @@ def barrier(world):
 
 
 def apply(eng, pf, src, dst, fmt, interp):
+    if pf.family == "packed":
+        return eng.apply_packed(src[0], dst[0], pix_fmt=fmt, interp=interp)
     if pf.family == "gbr":
         return eng.apply_rgb(src, dst, depth=pf.depth, interp=interp)
     return eng.apply_yuv(src, dst, pix_fmt=fmt, interp=interp)
@@ -93,6 +95,15 @@ def apply(eng, pf, src, dst, fmt, interp):
 def build_batch(eng, pf, w, h, r0, r1, nframes, dist_name, unique):
     """Rows [r0,r1) of `unique` synthetic frames, tiled to `nframes` frames on the device."""
     from lut_renderer_amd import frames
+    if pf.family == "packed":                            # interleave the planar RGB generator's frames
+        imgs = []
+        for k in range(unique):
+            g, b, r = (frames.natural_rgb if dist_name == "natural" else frames.uniform_rgb)(w, h, pf.depth, k=k)
+            img = np.full((r1 - r0, w, pf.nc), (1 << pf.depth) - 1, dtype=g.dtype)
+            img[..., pf.rgb[0]], img[..., pf.rgb[1]], img[..., pf.rgb[2]] = r[r0:r1], g[r0:r1], b[r0:r1]
+            imgs.append(torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img))
+        u = torch.stack(imgs).to(eng.device)
+        return [u.repeat((nframes + unique - 1) // unique, 1, 1, 1)[:nframes].contiguous()]
     bh = 1 << pf.csy
     planes = [[], [], []]
     for k in range(unique):
@@ -181,7 +192,13 @@ def main():
     from lut_renderer_amd.shard import my_rows
 
     w, h = SIZES[args.size]
-    pf = parse_pix_fmt(args.fmt)
+    from lut_renderer_amd._native import PACKED_FORMATS
+    if args.fmt in PACKED_FORMATS:
+        from types import SimpleNamespace
+        bits, nc, *rgb = PACKED_FORMATS[args.fmt]
+        pf = SimpleNamespace(family="packed", depth=bits, csx=0, csy=0, nc=nc, rgb=rgb)
+    else:
+        pf = parse_pix_fmt(args.fmt)
     eng = LutEngine(local)
     eng.set_variant(args.variant)
 
@@ -256,7 +273,8 @@ def main():
                              "separate streams; PCIe Gen5 x16-bound (63 GB/s per direction spec)"}
         log(f"[host pipeline] {host_pipe}")
     if rank == 0:
-        bpp_in = (3.0 if pf.family == "gbr" else 1.0 + 2.0 / (1 << (pf.csx + pf.csy))) * (1 if pf.depth <= 8 else 2)
+        bpp_in = (float(pf.nc) if pf.family == "packed" else 3.0 if pf.family == "gbr"
+                  else 1.0 + 2.0 / (1 << (pf.csx + pf.csy))) * (1 if pf.depth <= 8 else 2)
         bpp = 2.0 * bpp_in                                        # in + out, same format
         lattice_bytes = 3 * args.lut ** 3 * 4
         bytes_launch = bpp * px_rank + lattice_bytes              # per launch on one GPU
@@ -293,7 +311,7 @@ def main():
             result["extra_Mpx_s"] = extra
         if host_pipe:
             result["host_pipeline"] = host_pipe
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and pf.family != "packed":
             result["cpu_baseline"] = cpu_baseline(lut, pf, w, h, args.interp, args.dist, args.cpu_seconds)
         elif world > 1:
             result["cpu_baseline"] = None          # timed on rank 0 at N=1 only

@@ -165,6 +165,11 @@ int  lutr_ctx_set_lut(lutr_ctx *ctx, const float *rgb, int n, const float scale[
  * called lutr_ctx_set_lut), then every rank may apply. */
 int  lutr_ctx_lut_alloc(lutr_ctx *ctx, int n, const float scale[3]);
 int  lutr_ctx_lut_device(lutr_ctx *ctx, void **dptr, size_t *bytes);
+/* call after writing the device lattice obtained from lutr_ctx_lut_device (e.g. once the broadcast
+ * has landed): checks that every node is finite (LUTR_EINVAL otherwise, like lutr_ctx_set_lut) and
+ * records the lattice's value range, which selects clip-free kernels for lattices inside [0, 1].
+ * Optional: an unsealed lattice is applied with the general kernels. */
+int  lutr_ctx_lut_seal(lutr_ctx *ctx);
 /* bytes of the device lattice layout for size n: (n+1)^3 nodes of 16 bytes */
 size_t lutr_lattice_bytes(int n);
 

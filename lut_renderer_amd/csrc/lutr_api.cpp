@@ -164,6 +164,7 @@ struct lutr_ctx {
     float scale[3] = {1.f, 1.f, 1.f};
     int variant = VAR_AUTO;
     std::string last_kernel;
+    bool unit = false;               // every lattice node known to lie in [0, 1]
     unsigned *queue = nullptr;       // work-queue counter of the tile kernels (device), zeroed per launch
     unsigned *stats = nullptr;       // 8 device counters (4 reported + clock stamps), see lutr_ctx_tile_stats
 };
@@ -318,6 +319,7 @@ static int alloc_lattice(lutr_ctx *c, int n, const float scale[3])
         c->lat_bytes = bytes;
     }
     c->n = n;
+    c->unit = false;                 // unknown until the nodes are seen (lutr_ctx_set_lut / lutr_ctx_lut_seal)
     std::memcpy(c->scale, scale, sizeof(c->scale));
     return LUTR_OK;
 }
@@ -328,11 +330,14 @@ int lutr_ctx_set_lut(lutr_ctx *c, const float *rgb, int n, const float scale[3])
 {
     if (!rgb) { set_error("null lattice"); return LUTR_EINVAL; }
     const size_t count = (size_t)(n > 0 ? n : 0) * n * n * 3;
-    for (size_t i = 0; i < count && n >= 2 && n <= 256; i++)
+    bool unit = true;
+    for (size_t i = 0; i < count && n >= 2 && n <= 256; i++) {
         if (!std::isfinite(rgb[i])) {
             set_error("non-finite lattice value at float %zu", i);
             return LUTR_EINVAL;
         }
+        unit = unit && rgb[i] >= 0.0f && rgb[i] <= 1.0f;
+    }
     const int rc = alloc_lattice(c, n, scale);
     if (rc) return rc;
     // pack [r][g][b][3] -> (n+1)^3 float4 with the last node replicated on each axis
@@ -351,6 +356,31 @@ int lutr_ctx_set_lut(lutr_ctx *c, const float *rgb, int n, const float scale[3])
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->lat, host.data(), c->lat_bytes, hipMemcpyHostToDevice));
+    c->unit = unit;
+    return LUTR_OK;
+}
+
+int lutr_ctx_lut_seal(lutr_ctx *c)
+{
+    if (!c) { set_error("null argument"); return LUTR_EINVAL; }
+    if (!c->lat) { set_error("no lattice set on this context"); return LUTR_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float4> host(c->lat_bytes / sizeof(float4));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host.data(), c->lat, c->lat_bytes, hipMemcpyDeviceToHost));
+    bool unit = true;
+    for (size_t i = 0; i < host.size(); i++) {
+        const float v[3] = {host[i].x, host[i].y, host[i].z};
+        for (int k = 0; k < 3; k++) {
+            if (!std::isfinite(v[k])) {
+                c->unit = false;
+                set_error("non-finite lattice value at node %zu", i);
+                return LUTR_EINVAL;
+            }
+            unit = unit && v[k] >= 0.0f && v[k] <= 1.0f;
+        }
+    }
+    c->unit = unit;
     return LUTR_OK;
 }
 
@@ -397,6 +427,7 @@ static void fill_lut(LutConsts *L, const lutr_ctx *c, int depth)
     L->lat = c->lat;
     L->n1 = c->n + 1;
     L->maxf = (float)maxi;
+    L->unit = c->unit ? 1 : 0;
     L->scale_f = 1.0f / (float)maxi;
     L->lut_max = (float)(c->n - 1);
     for (int i = 0; i < 3; i++) L->sc[i] = c->scale[i] * L->lut_max;

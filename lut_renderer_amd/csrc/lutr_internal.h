@@ -20,6 +20,7 @@ struct LutConsts {
     float sc[3];         // scale.{r,g,b} * (n-1)
     float lut_max;       // (float)(n-1)
     float maxf;          // (float)(2^depth - 1)
+    int   unit;          // 1 when every lattice node is known to lie in [0, 1] (lets the tile kernels drop the output clip)
 };
 
 // Constant block of the YUV contract; same fields, same order as the

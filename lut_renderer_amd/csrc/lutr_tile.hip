@@ -235,12 +235,23 @@ __device__ __forceinline__ Rgb3 px_blend(const LutConsts &L, const Win &W, const
     return v;
 }
 
+// (int)(v * M) clipped to [0, M].  UNIT: every lattice node lies in [0, 1] (checked on the host when
+// the lattice is set), so the nearest / trilinear / tetrahedral blends stay in [0, 1 + a few ulp]:
+// all weights and nodes are >= 0 and the rounding of each product and sum is monotone, hence
+// 0 <= v * M < M + 1 and the truncation alone already lands in [0, M]; the clip is dead code.
+template <bool UNIT>
 __device__ __forceinline__ Rgb3 px_quant(const LutConsts &L, const Rgb3 &v)
 {
     Rgb3 o;
-    o.r = tmed3(truncf(v.r * L.maxf), 0.0f, L.maxf);
-    o.g = tmed3(truncf(v.g * L.maxf), 0.0f, L.maxf);
-    o.b = tmed3(truncf(v.b * L.maxf), 0.0f, L.maxf);
+    if constexpr (UNIT) {
+        o.r = truncf(v.r * L.maxf);
+        o.g = truncf(v.g * L.maxf);
+        o.b = truncf(v.b * L.maxf);
+    } else {
+        o.r = tmed3(truncf(v.r * L.maxf), 0.0f, L.maxf);
+        o.g = tmed3(truncf(v.g * L.maxf), 0.0f, L.maxf);
+        o.b = tmed3(truncf(v.b * L.maxf), 0.0f, L.maxf);
+    }
     return o;
 }
 
@@ -248,7 +259,7 @@ template <bool LDS, int INTERP>
 __device__ __forceinline__ Rgb3 lut_px(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
 {
     const PxC c = px_coords<LDS, INTERP>(L, W, rc, gc, bc, bn);
-    return px_quant(L, px_blend<LDS, INTERP>(L, W, c));
+    return px_quant<false>(L, px_blend<LDS, INTERP>(L, W, c));
 }
 
 // ---------------------------------------------------------------- window management
@@ -435,7 +446,7 @@ struct YuvTile {
     uint32_t y[BH][YW], cb[CW], cr[CW];
 };
 
-template <bool LDS, int WIDE, int CSX, int CSY, int INTERP, bool PRE, bool TAB>
+template <bool LDS, int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
 __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConsts &K, const Win &W,
                                               YuvTile<WIDE, CSX, CSY> &in, YuvTile<WIDE, CSX, CSY> &out, Bnd &bn)
 {
@@ -486,7 +497,7 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
         // ---- stage B: taps and blend (pairs keep 8 reads in flight), stage C: outputs
         Rgb3 o[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) o[p] = px_quant(L, px_blend<LDS, INTERP>(L, W, pc[p]));
+        for (int p = 0; p < 4; p++) o[p] = px_quant<TAB == 2>(L, px_blend<LDS, INTERP>(L, W, pc[p]));
         float rs[NCG], gs[NCG], bs[NCG];
 #pragma unroll
         for (int c = 0; c < NCG; c++) { rs[c] = 0.f; gs[c] = 0.f; bs[c] = 0.f; }
@@ -515,7 +526,7 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
 // Bounds-only pass: the cells a tile touches, without taps, blend or outputs (about a quarter of a full
 // pass).  Run on the first tile of a chunk, where the wave's window comes from somewhere else on the
 // frame and an optimistic full pass would almost surely be thrown away.  Does not consume `in`.
-template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, bool TAB>
+template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
 __device__ __forceinline__ void yuv_tile_bounds(const LutConsts &L, const YuvConsts &K, YuvTile<WIDE, CSX, CSY> &in, Bnd &bn)
 {
     // consumes `in` like the full body (ordering fences), so the caller re-loads the tile afterwards
@@ -578,7 +589,7 @@ __device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &f
     return true;
 }
 
-template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, bool TAB>
+template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
 void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG)
 {
@@ -713,7 +724,7 @@ __device__ __forceinline__ unsigned wcode(const uint32_t *w, int i)
     else return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
 }
 
-template <bool LDS, int WIDE, int INTERP, bool TAB>
+template <bool LDS, int WIDE, int INTERP, int TAB>
 __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, RgbTile<WIDE> &in,
                                               RgbTile<WIDE> &out, Bnd &bn)
 {
@@ -738,7 +749,7 @@ __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, 
         }
         Rgb3 o[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) o[p] = px_quant(L, px_blend<LDS, INTERP>(L, W, pc[p]));
+        for (int p = 0; p < 4; p++) o[p] = px_quant<TAB == 2>(L, px_blend<LDS, INTERP>(L, W, pc[p]));
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int i = g * 4 + p;
@@ -751,7 +762,7 @@ __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, 
     }
 }
 
-template <int WIDE, int INTERP, bool TAB>
+template <int WIDE, int INTERP, int TAB>
 __device__ __forceinline__ void rgb_tile_bounds(const LutConsts &L, RgbTile<WIDE> &in, Bnd &bn)
 {
 #pragma unroll
@@ -772,7 +783,7 @@ __device__ __forceinline__ void rgb_tile_bounds(const LutConsts &L, RgbTile<WIDE
     }
 }
 
-template <int WIDE, int INTERP, bool TAB>
+template <int WIDE, int INTERP, int TAB>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
 void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
 {
@@ -780,7 +791,6 @@ void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
     using T = RgbTile<WIDE>;
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
-    const int wave = blockIdx.x * 4 + wib;
     const int slice_off = TG.tab_bytes + wib * TG.win_nodes * 16;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
@@ -955,9 +965,10 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     const size_t lds = (size_t)tg.tab_bytes + (size_t)4 * tg.win_nodes * 16;
 #define RGB_CASE(W, I) \
     if (wide == W && mode == I) { \
-        if (tab) hipLaunchKernelGGL((k_rgb_tile<W, I, true>), grid, block, lds, st, L, P, G, tg); \
-        else hipLaunchKernelGGL((k_rgb_tile<W, I, false>), grid, block, lds, st, L, P, G, tg); \
-        return tab ? "k_rgb_tile<" #W "," #I ",tab>" : "k_rgb_tile<" #W "," #I ">"; \
+        if (tab && L.unit) hipLaunchKernelGGL((k_rgb_tile<W, I, 2>), grid, block, lds, st, L, P, G, tg); \
+        else if (tab) hipLaunchKernelGGL((k_rgb_tile<W, I, 1>), grid, block, lds, st, L, P, G, tg); \
+        else hipLaunchKernelGGL((k_rgb_tile<W, I, 0>), grid, block, lds, st, L, P, G, tg); \
+        return tab ? (L.unit ? "k_rgb_tile<" #W "," #I ",tab,unit>" : "k_rgb_tile<" #W "," #I ",tab>") : "k_rgb_tile<" #W "," #I ">"; \
     }
     RGB_CASE(0, 0) RGB_CASE(0, 1) RGB_CASE(0, 2)
     RGB_CASE(1, 0) RGB_CASE(1, 1) RGB_CASE(1, 2)
@@ -979,18 +990,20 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     const bool pre = K.pre != 0.0f;
     if (getenv("LUTR_DEBUG")) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false, true>, 256, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false, 1>, 256, lds);
         fprintf(stderr, "[lutr] tiles %d nsx %d nry %d chunk %d nrc %d chunks %d blocks %u lds/block %zu occupancy(blocks/CU) %d cus %d\n",
                 tg.tiles, tg.nsx, tg.nry, tg.ch, tg.nrc, tg.nchunks, grid.x, lds, nb, device_cus());
     }
 #define YUV_CASE(W, X, Y, I) \
     if (win == W && csx == X && csy == Y && mode == I) { \
-        if (pre && tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, true>), grid, block, lds, st, L, K, P, G, tg); \
-        else if (pre) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, false>), grid, block, lds, st, L, K, P, G, tg); \
-        else if (tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, true>), grid, block, lds, st, L, K, P, G, tg); \
-        else hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, false>), grid, block, lds, st, L, K, P, G, tg); \
+        if (pre && tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, 1>), grid, block, lds, st, L, K, P, G, tg); \
+        else if (pre) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, 0>), grid, block, lds, st, L, K, P, G, tg); \
+        else if (tab && L.unit) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 2>), grid, block, lds, st, L, K, P, G, tg); \
+        else if (tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 1>), grid, block, lds, st, L, K, P, G, tg); \
+        else hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 0>), grid, block, lds, st, L, K, P, G, tg); \
         return pre ? (tab ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre,tab>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre>") \
-                   : (tab ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"); \
+                   : (tab ? (L.unit ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab,unit>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab>") \
+                          : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"); \
     }
 #define YUV_FMT(W, X, Y) YUV_CASE(W, X, Y, 0) YUV_CASE(W, X, Y, 1) YUV_CASE(W, X, Y, 2)
     YUV_FMT(0, 1, 1) YUV_FMT(0, 1, 0) YUV_FMT(0, 0, 0)

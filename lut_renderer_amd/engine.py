@@ -168,6 +168,9 @@ class LutEngine:
             _native.check(self._lib.lutr_ctx_lut_alloc(self._ctx, n, scale))
             self.n, self.scale = n, np.array(list(scale), dtype=np.float32)
         dist.broadcast(self.lattice_tensor(), src=src, group=group)
+        if rank != src:
+            torch.cuda.current_stream(self.device).synchronize()
+            _native.check(self._lib.lutr_ctx_lut_seal(self._ctx))      # finiteness + value range of what arrived
 
     # -- control ----------------------------------------------------------
     def set_variant(self, name: str) -> None:

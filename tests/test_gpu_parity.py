@@ -398,3 +398,62 @@ def test_packed_rgb_batches_shards_in_place_and_padding(engine, orc, cube_dir):
         engine.apply_packed(view, pix_fmt="rgb48le")
     with pytest.raises(ValueError):
         engine.apply_packed(view, pix_fmt="rgb565")
+
+
+def test_unit_range_lattices_use_the_clip_free_kernels_and_others_do_not(engine, orc, cube_dir):
+    """A lattice inside [0,1] selects the tile kernels without the output clip (provably dead code);
+    anything else keeps it.  Both against the oracle, including the lattices that sit on the bounds."""
+    from lut_renderer_amd.cube import CubeLut
+    rng = np.random.default_rng(5)
+    base = cube.log709_lattice(17)
+    edge = rng.choice(np.array([0.0, 1.0, 1e-30, 1.0 - 2.0 ** -24, 0.5], dtype=np.float32), size=(9, 9, 9, 3))
+    cases = [("ones", np.ones((5, 5, 5, 3), np.float32), True), ("zeros", np.zeros((5, 5, 5, 3), np.float32), True),
+             ("edge", edge, True), ("log709", base, True), ("identity", cube.identity_lattice(33), True),
+             ("wide", (base * 1.3 - 0.15).astype(np.float32), False),
+             ("just_above", np.where(base >= 1.0, np.float32(1.0 + 2.0 ** -23), base).astype(np.float32), False),
+             ("just_below", np.where(base <= 0.0, np.float32(-1e-38), base).astype(np.float32), False)]
+    k10, k8 = orc.yuv_constants(din=10), orc.yuv_constants(din=8)
+    for name, tab, unit in cases:
+        lut = CubeLut(tab.shape[0], np.ones(3, dtype=np.float32), tab)
+        engine.set_lut(lut)
+        for mode in MODES3:
+            for depth, kk, fmt in ((10, k10, "yuv420p10le"), (8, k8, "yuv420p")):
+                src = frames.uniform_yuv(256, 64, depth, 1, 1, k=3)
+                got = engine.apply_yuv(_to_dev(src, engine), pix_fmt=fmt, interp=mode)
+                assert ("unit" in engine.last_kernel) == unit, (name, engine.last_kernel)
+                want = orc.apply_yuv(tab, lut.scale, mode, kk, depth, depth, depth, 1, 1, src)
+                _assert_equal(_to_np(got, src[0].dtype), want, f"unit/{name} {mode} {fmt}")
+            rgb = frames.uniform_rgb(256, 36, 10, k=4)
+            got = engine.apply_rgb(_to_dev(rgb, engine), depth=10, interp=mode)
+            assert ("unit" in engine.last_kernel) == unit
+            _assert_equal(_to_np(got, np.uint16), orc.apply_rgb(tab, lut.scale, 10, mode, rgb), f"unit/{name} {mode} rgb")
+
+
+def test_seal_records_range_and_rejects_non_finite(cube_dir):
+    """lutr_ctx_lut_alloc + a write through lutr_ctx_lut_device (what a broadcast does) + lutr_ctx_lut_seal."""
+    import ctypes as C
+    from lut_renderer_amd import _native
+    from lut_renderer_amd.engine import LutEngine
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    src = frames.natural_yuv(256, 64, 10, 1, 1, k=1)
+    with LutEngine(0) as a, LutEngine(0) as b:
+        a.set_lut(lut)
+        want = a.apply_yuv(_to_dev(src, a), pix_fmt="yuv420p10le")
+        assert "unit" in a.last_kernel
+        scale = (C.c_float * 3)(1.0, 1.0, 1.0)
+        _native.check(b._lib.lutr_ctx_lut_alloc(b._ctx, 33, scale))
+        b.n, b.scale = 33, np.ones(3, np.float32)
+        b.lattice_tensor().copy_(a.lattice_tensor())
+        torch.cuda.synchronize()
+        got = b.apply_yuv(_to_dev(src, b), pix_fmt="yuv420p10le")
+        assert "tile" in b.last_kernel and "unit" not in b.last_kernel      # unsealed: general kernel
+        _native.check(b._lib.lutr_ctx_lut_seal(b._ctx))
+        got2 = b.apply_yuv(_to_dev(src, b), pix_fmt="yuv420p10le")
+        assert "unit" in b.last_kernel
+        for x, y, z in zip(want, got, got2):
+            assert torch.equal(x, y) and torch.equal(x, z)
+        b.lattice_tensor()[5] = float("nan")
+        torch.cuda.synchronize()
+        with pytest.raises(_native.LutrError) as ei:
+            _native.check(b._lib.lutr_ctx_lut_seal(b._ctx))
+        assert ei.value.code == _native.EINVAL
