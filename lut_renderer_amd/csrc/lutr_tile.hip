@@ -96,10 +96,18 @@ __device__ __forceinline__ void bnd_update(Bnd &bn, float pr, float pg, float pb
     bn.bmin = fminf(bn.bmin, hb); bn.bmax = fmaxf(bn.bmax, hb);
 }
 
+// LDS taps take an ABSOLUTE LDS byte address (the window constants include lds_base()): going
+// through `lutr_smem + a` costs a v_add_u32 with the relocated symbol per pixel.
+typedef const __attribute__((address_space(3))) f4 lds_f4;
+__device__ __forceinline__ int lds_base()
+{
+    return (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lutr_smem;
+}
+
 template <bool LDS>
 __device__ __forceinline__ f4 tap(const float4 *__restrict__ lat, int a)
 {
-    if constexpr (LDS) return *(const f4 *)(lutr_smem + a);
+    if constexpr (LDS) return *(lds_f4 *)(uintptr_t)(unsigned)a;
     else return *(const f4 *)((const char *)lat + a);
 }
 
@@ -179,8 +187,11 @@ __device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const
         const int o111 = o_r + o_g + o_b;
         const int z_r = o111 - o_r, z_g = o111 - o_g, z_b = o111 - o_b;
         // first step along the axis of the largest fraction, last step along the smallest
-        c.oa = (rg && rb) ? o_r : ((!rg && gb) ? o_g : o_b);
-        c.oz = (gb && rb) ? z_b : ((!gb && rg) ? z_g : z_r);
+        // Written without negations (each would become one more v_cmp): when r is not the strict maximum,
+        // g > b already makes g a maximum (r <= g or r <= b < g); when b is not the strict minimum, r > g
+        // already makes g a minimum.  Ties only ever pick between taps whose weight is exactly 0.
+        c.oa = (rg && rb) ? o_r : (gb ? o_g : o_b);
+        c.oz = (gb && rb) ? z_b : (rg ? z_g : z_r);
         c.w0 = 1.0f - x; c.w1 = x - y; c.w2 = y - z; c.w3 = z;
     }
     return c;
@@ -255,13 +266,6 @@ __device__ __forceinline__ Rgb3 px_quant(const LutConsts &L, const Rgb3 &v)
     return o;
 }
 
-template <bool LDS, int INTERP>
-__device__ __forceinline__ Rgb3 lut_px(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
-{
-    const PxC c = px_coords<LDS, INTERP>(L, W, rc, gc, bc, bn);
-    return px_quant<false>(L, px_blend<LDS, INTERP>(L, W, c));
-}
-
 // ---------------------------------------------------------------- window management
 __device__ __forceinline__ void win_global(Win &W, const LutConsts &L)
 {
@@ -277,9 +281,9 @@ __device__ __forceinline__ void win_global(Win &W, const LutConsts &L)
 // (harmless), and the admissible set is empty so the pass is always declared a miss.
 __device__ __forceinline__ void win_empty(Win &W, int slice_off)
 {
-    W.fr = W.fg = W.fb = 0.0f; W.fc = (float)slice_off;
+    W.fr = W.fg = W.fb = 0.0f; W.fc = (float)(lds_base() + slice_off);
     W.o_r = W.o_g = W.o_b = 0;
-    W.a_max = (unsigned)slice_off;
+    W.a_max = (unsigned)(lds_base() + slice_off);
     W.r_lo = W.g_lo = W.b_lo = 1.0f;
     W.r_hi = W.g_hi = W.b_hi = 0.0f;
 }
@@ -335,8 +339,8 @@ __device__ __forceinline__ bool win_restage(Win &W, const LutConsts &L, const Bn
     // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pr-b0)
     W.o_r = 16 * (sr - nb - 1); W.o_g = 16 * nb; W.o_b = 16;
     W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = 16.0f;
-    W.fc = (float)(slice_off - 16 * (r0 * sr + g0 * nb + b0));
-    W.a_max = (unsigned)(lds_bytes - (W.o_r + W.o_g + W.o_b) - 16);
+    W.fc = (float)(lds_base() + slice_off - 16 * (r0 * sr + g0 * nb + b0));
+    W.a_max = (unsigned)(lds_base() + lds_bytes - (W.o_r + W.o_g + W.o_b) - 16);
     W.r_lo = (float)r0;       W.r_hi = (float)(r0 + nr - 2);
     W.g_lo = (float)(g0 + 1); W.g_hi = (float)(g0 + ng - 2);
     W.b_lo = (float)(b0 + 1); W.b_hi = (float)(b0 + nb - 2);
@@ -406,7 +410,9 @@ __device__ __forceinline__ void fence_words(uint32_t *w)
 __device__ __forceinline__ float cfloor(float v, float hi) { return tmed3(floorf(v), 0.0f, hi); }
 // RGB -> YUV side: Y and chroma are positive-offset convex mixes of codes in [0, M], so they cannot go
 // below 0; only full-range chroma can reach M+1 (128.5 + 127.5 at 8 bit).  Upper bound only.
-__device__ __forceinline__ float ofloor(float v, float hi) { return fminf(floorf(v), hi); }
+// The float -> unsigned conversion of wput() is the floor (v_cvt_u32_f32 truncates; the values are >= 0)
+// and hi is an integer, so min(floor(v), hi) == floor(min(v, hi)): no separate v_floor_f32.
+__device__ __forceinline__ float ofloor(float v, float hi) { return fminf(v, hi); }
 
 // ---------------------------------------------------------------- tile geometry
 struct TileGeom {
@@ -431,7 +437,7 @@ struct TileGeom {
 // LUTR_UNIT_HALF the unit is 8 bytes of luma per row instead of 16: half the input / output /
 // prefetch registers per lane (more waves per SIMD) at twice the per-tile overhead per pixel.
 #ifndef LUTR_PIN_CONSTS
-#define LUTR_PIN_CONSTS 0
+#define LUTR_PIN_CONSTS 1
 #endif
 #ifndef LUTR_UNIT_HALF
 #define LUTR_UNIT_HALF 0
@@ -498,13 +504,14 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
         Rgb3 o[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) o[p] = px_quant<TAB == 2>(L, px_blend<LDS, INTERP>(L, W, pc[p]));
+        // chroma block sums: integer codes (exact in fp32 in any order); the first pixel of a block
+        // initialises its sum (a literal 0 + x is not foldable without fast-math and costs an add)
         float rs[NCG], gs[NCG], bs[NCG];
-#pragma unroll
-        for (int c = 0; c < NCG; c++) { rs[c] = 0.f; gs[c] = 0.f; bs[c] = 0.f; }
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
-            rs[c] += o[p].r; gs[c] += o[p].g; bs[c] += o[p].b;
+            if (dy == 0 && ((p % GW) & (T::BW - 1)) == 0) { rs[c] = o[p].r; gs[c] = o[p].g; bs[c] = o[p].b; }
+            else { rs[c] += o[p].r; gs[c] += o[p].g; bs[c] += o[p].b; }
             wput<WIDE>(out.y[dy], i, ofloor(tfma(K.cyr, o[p].r, tfma(K.cyg, o[p].g, tfma(K.cyb, o[p].b, K.yob))), K.max_o));
         }
 #pragma unroll
@@ -595,7 +602,8 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
 {
     LutConsts L = L_;
     YuvConsts K = K_;
-    if (LUTR_PIN_CONSTS) {      // used 3-6 times per pixel by full-rate ops
+    // used 3 times per pixel each by full-rate ops (see in_vgpr); the trilinear bodies have no registers to spare
+    if constexpr (LUTR_PIN_CONSTS && INTERP != LUTR_INTERP_TRILINEAR) {
         L.maxf = in_vgpr(L_.maxf);
         K.cyr = in_vgpr(K_.cyr); K.cyg = in_vgpr(K_.cyg); K.cyb = in_vgpr(K_.cyb);
     }
@@ -785,8 +793,10 @@ __device__ __forceinline__ void rgb_tile_bounds(const LutConsts &L, RgbTile<WIDE
 
 template <int WIDE, int INTERP, int TAB>
 __global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
-void k_rgb_tile(LutConsts L, PlaneSet P, FrameGeom G, TileGeom TG)
+void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
 {
+    LutConsts L = L_;
+    if constexpr (LUTR_PIN_CONSTS && INTERP != LUTR_INTERP_TRILINEAR) L.maxf = in_vgpr(L_.maxf);
     if constexpr (TAB) coord_table_fill<INTERP>(L, TG.tab_bytes / 8);
     using T = RgbTile<WIDE>;
     const int lane = threadIdx.x & 63;
