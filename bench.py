@@ -43,8 +43,8 @@ def log(*a):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (SURVEY 8d: >= 64)")
     ap.add_argument("--size", default="uhd", choices=sorted(SIZES))
     ap.add_argument("--fmt", default="yuv420p10le")
@@ -245,7 +245,7 @@ def main():
         for dname in ("natural", "uniform"):
             for mode in ("tetrahedral", "trilinear"):
                 s2 = build_batch(eng, pf, w, h, r0, r1, nframes, dname, args.unique)
-                _, k2 = time_steps(eng, pf, s2, dst, args.fmt, mode, max(3, args.steps // 2), 2, 1)
+                _, k2 = time_steps(eng, pf, s2, dst, args.fmt, mode, max(3, args.steps // 2), max(2, args.warmup // 2), 1)
                 extra[f"{dname}/{mode}"] = round(px_rank / k2 / 1e6, 1)
                 eng.tile_stats(True)
                 apply(eng, pf, s2, dst, args.fmt, mode)

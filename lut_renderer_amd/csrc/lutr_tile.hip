@@ -96,6 +96,31 @@ __device__ __forceinline__ void bnd_update(Bnd &bn, float pr, float pg, float pb
     bn.bmin = fminf(bn.bmin, hb); bn.bmax = fmaxf(bn.bmax, hb);
 }
 
+// Sheared cell coordinates of one pixel, and the bounds update for a PAIR of pixels: v_min3 / v_max3
+// fold two pixels per instruction (3 slow-class VALU per pixel instead of 6).  Written as asm because
+// hipcc only forms min3/max3 from some of the equivalent fminf/fmaxf chains.
+struct Cell { float r, hg, hb; };
+
+__device__ __forceinline__ float vmin3(float a, float b, float c)
+{
+    float o;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float o;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+
+__device__ __forceinline__ void bnd_update2(Bnd &bn, const Cell &a, const Cell &b)
+{
+    bn.rmin = vmin3(bn.rmin, a.r, b.r);    bn.rmax = vmax3(bn.rmax, a.r, b.r);
+    bn.gmin = vmin3(bn.gmin, a.hg, b.hg);  bn.gmax = vmax3(bn.gmax, a.hg, b.hg);
+    bn.bmin = vmin3(bn.bmin, a.hb, b.hb);  bn.bmax = vmax3(bn.bmax, a.hb, b.hb);
+}
+
 // LDS taps take an ABSOLUTE LDS byte address (the window constants include lds_base()): going
 // through `lutr_smem + a` costs a v_add_u32 with the relocated symbol per pixel.
 typedef const __attribute__((address_space(3))) f4 lds_f4;
@@ -160,10 +185,10 @@ __device__ __forceinline__ void coord_table_fill(const LutConsts &L, int entries
 }
 
 template <bool LDS, int INTERP>
-__device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const Crd &cr, const Crd &cg, const Crd &cb, Bnd &bn)
+__device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const Crd &cr, const Crd &cg, const Crd &cb, Cell &cell)
 {
     const float pr = cr.p, pg = cg.p, pb = cb.p;
-    bnd_update(bn, pr, pg, pb);
+    cell.r = pr; cell.hg = pg - pr; cell.hb = pb - pr;
     PxC c;
     if constexpr (LDS) {
         // exact in fp32: every term is an integer well below 2^24 for a window of <= 4096 nodes
@@ -199,17 +224,17 @@ __device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const
 
 // float codes (already clipped to [0, M]) -> PxC, computed coordinates
 template <bool LDS, int INTERP>
-__device__ __forceinline__ PxC px_coords(const LutConsts &L, const Win &W, float rc, float gc, float bc, Bnd &bn)
+__device__ __forceinline__ PxC px_coords(const LutConsts &L, const Win &W, float rc, float gc, float bc, Cell &cell)
 {
     return px_finish<LDS, INTERP>(L, W, crd_compute<INTERP>(L, rc, L.sc[0]), crd_compute<INTERP>(L, gc, L.sc[1]),
-                                  crd_compute<INTERP>(L, bc, L.sc[2]), bn);
+                                  crd_compute<INTERP>(L, bc, L.sc[2]), cell);
 }
 
 // integer codes in [0, M] -> PxC, table coordinates
 template <bool LDS, int INTERP>
-__device__ __forceinline__ PxC px_coords_tab(const LutConsts &L, const Win &W, unsigned ri, unsigned gi, unsigned bi, Bnd &bn)
+__device__ __forceinline__ PxC px_coords_tab(const LutConsts &L, const Win &W, unsigned ri, unsigned gi, unsigned bi, Cell &cell)
 {
-    return px_finish<LDS, INTERP>(L, W, crd_table(ri), crd_table(gi), crd_table(bi), bn);
+    return px_finish<LDS, INTERP>(L, W, crd_table(ri), crd_table(gi), crd_table(bi), cell);
 }
 
 template <bool LDS, int INTERP>
@@ -412,7 +437,14 @@ __device__ __forceinline__ float cfloor(float v, float hi) { return tmed3(floorf
 // below 0; only full-range chroma can reach M+1 (128.5 + 127.5 at 8 bit).  Upper bound only.
 // The float -> unsigned conversion of wput() is the floor (v_cvt_u32_f32 truncates; the values are >= 0)
 // and hi is an integer, so min(floor(v), hi) == floor(min(v, hi)): no separate v_floor_f32.
-__device__ __forceinline__ float ofloor(float v, float hi) { return fminf(v, hi); }
+// DEAD: the launcher evaluated the same fma chains at their maxima (out_clip_dead) and found them
+// below hi + 1, so even the upper bound cannot bind.
+template <bool DEAD>
+__device__ __forceinline__ float ofloor(float v, float hi)
+{
+    if constexpr (DEAD) return v;
+    else return fminf(v, hi);
+}
 
 // ---------------------------------------------------------------- tile geometry
 struct TileGeom {
@@ -483,6 +515,7 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
             rv[c] = K.krv * crd; gv[c] = tfma(K.kgu, cbd, K.kgv * crd); bu[c] = K.kbu * cbd;
         }
         PxC pc[4];
+        Cell cell[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
@@ -494,11 +527,12 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
                 const unsigned mi = (unsigned)K.max_l;
                 const unsigned ri = min((unsigned)(yy + rv[c]), mi), gi = min((unsigned)(yy + gv[c]), mi),
                                bi = min((unsigned)(yy + bu[c]), mi);
-                pc[p] = px_coords_tab<LDS, INTERP>(L, W, ri, gi, bi, bn);
+                pc[p] = px_coords_tab<LDS, INTERP>(L, W, ri, gi, bi, cell[p]);
             } else {
                 const float rq = cfloor(yy + rv[c], K.max_l), gq = cfloor(yy + gv[c], K.max_l), bq = cfloor(yy + bu[c], K.max_l);
-                pc[p] = px_coords<LDS, INTERP>(L, W, rq, gq, bq, bn);
+                pc[p] = px_coords<LDS, INTERP>(L, W, rq, gq, bq, cell[p]);
             }
+            if (p & 1) bnd_update2(bn, cell[p - 1], cell[p]);
         }
         // ---- stage B: taps and blend (pairs keep 8 reads in flight), stage C: outputs
         Rgb3 o[4];
@@ -512,13 +546,13 @@ __device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConst
             const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
             if (dy == 0 && ((p % GW) & (T::BW - 1)) == 0) { rs[c] = o[p].r; gs[c] = o[p].g; bs[c] = o[p].b; }
             else { rs[c] += o[p].r; gs[c] += o[p].g; bs[c] += o[p].b; }
-            wput<WIDE>(out.y[dy], i, ofloor(tfma(K.cyr, o[p].r, tfma(K.cyg, o[p].g, tfma(K.cyb, o[p].b, K.yob))), K.max_o));
+            wput<WIDE>(out.y[dy], i, ofloor<TAB == 2>(tfma(K.cyr, o[p].r, tfma(K.cyg, o[p].g, tfma(K.cyb, o[p].b, K.yob))), K.max_o));
         }
 #pragma unroll
         for (int c = 0; c < NCG; c++) {
             const int j = g * NCG + c;
-            wput<WIDE>(out.cb, j, ofloor(tfma(K.cbr, rs[c], tfma(K.cbg, gs[c], tfma(K.cbb, bs[c], K.cob))), K.max_o));
-            wput<WIDE>(out.cr, j, ofloor(tfma(K.crr, rs[c], tfma(K.crg, gs[c], tfma(K.crb, bs[c], K.cob))), K.max_o));
+            wput<WIDE>(out.cb, j, ofloor<TAB == 2>(tfma(K.cbr, rs[c], tfma(K.cbg, gs[c], tfma(K.cbb, bs[c], K.cob))), K.max_o));
+            wput<WIDE>(out.cr, j, ofloor<TAB == 2>(tfma(K.crr, rs[c], tfma(K.crg, gs[c], tfma(K.crb, bs[c], K.cob))), K.max_o));
         }
         // emit the unit group by group (see fence_words)
         fence_words<T::YW * T::BH>(&in.y[0][0]);
@@ -743,6 +777,7 @@ __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, 
 #pragma unroll
     for (int g = 0; g < RgbTile<WIDE>::PXT / 4; g++) {
         PxC pc[4];
+        Cell cell[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int i = g * 4 + p;
@@ -750,10 +785,11 @@ __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, 
                 // codes above 2^depth-1 cannot occur in a valid plane; clamp so a stray one cannot index past the table
                 const unsigned mi = (unsigned)L.maxf;
                 pc[p] = px_coords_tab<LDS, INTERP>(L, W, min(wcode<WIDE>(in.r, i), mi), min(wcode<WIDE>(in.g, i), mi),
-                                                   min(wcode<WIDE>(in.b, i), mi), bn);
+                                                   min(wcode<WIDE>(in.b, i), mi), cell[p]);
             } else {
-                pc[p] = px_coords<LDS, INTERP>(L, W, wsample<WIDE>(in.r, i), wsample<WIDE>(in.g, i), wsample<WIDE>(in.b, i), bn);
+                pc[p] = px_coords<LDS, INTERP>(L, W, wsample<WIDE>(in.r, i), wsample<WIDE>(in.g, i), wsample<WIDE>(in.b, i), cell[p]);
             }
+            if (p & 1) bnd_update2(bn, cell[p - 1], cell[p]);
         }
         Rgb3 o[4];
 #pragma unroll
@@ -986,6 +1022,20 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     return nullptr;
 }
 
+// Can min(v, max_o) of the RGB -> YUV side ever bind?  Inputs are integer codes in [0, max_l] (sums of
+// chroma_n of them for Cb/Cr); every chain is monotone in each input (rounding is monotone), so its
+// maximum is the same float expression evaluated at the corner that maximises each term.
+static bool out_clip_dead(const YuvConsts &K, int chroma_n)
+{
+    const float m = K.max_l, mn = K.max_l * (float)chroma_n;
+    auto hi = [](float c, float v) { return c > 0.0f ? v : 0.0f; };
+    const float y = fmaf(K.cyr, hi(K.cyr, m), fmaf(K.cyg, hi(K.cyg, m), fmaf(K.cyb, hi(K.cyb, m), K.yob)));
+    const float cb = fmaf(K.cbr, hi(K.cbr, mn), fmaf(K.cbg, hi(K.cbg, mn), fmaf(K.cbb, hi(K.cbb, mn), K.cob)));
+    const float cr = fmaf(K.crr, hi(K.crr, mn), fmaf(K.crg, hi(K.crg, mn), fmaf(K.crb, hi(K.crb, mn), K.cob)));
+    const float lim = K.max_o + 1.0f;
+    return y < lim && cb < lim && cr < lim;
+}
+
 const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
                             const FrameGeom &G, int win, int csx, int csy, int mode, unsigned *stats, unsigned *queue)
 {
@@ -998,6 +1048,8 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     const bool tab = plan_table(&tg, L) != 0;
     const size_t lds = (size_t)tg.tab_bytes + (size_t)4 * tg.win_nodes * 16;
     const bool pre = K.pre != 0.0f;
+    // ",unit" kernels drop both output clips: lattice in [0,1] (quantisation) and YUV maxima below max_o + 1
+    const bool unit = L.unit && out_clip_dead(K, 1 << (csx + csy));
     if (getenv("LUTR_DEBUG")) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false, 1>, 256, lds);
@@ -1008,11 +1060,11 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     if (win == W && csx == X && csy == Y && mode == I) { \
         if (pre && tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, 1>), grid, block, lds, st, L, K, P, G, tg); \
         else if (pre) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, 0>), grid, block, lds, st, L, K, P, G, tg); \
-        else if (tab && L.unit) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 2>), grid, block, lds, st, L, K, P, G, tg); \
+        else if (tab && unit) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 2>), grid, block, lds, st, L, K, P, G, tg); \
         else if (tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 1>), grid, block, lds, st, L, K, P, G, tg); \
         else hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 0>), grid, block, lds, st, L, K, P, G, tg); \
         return pre ? (tab ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre,tab>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre>") \
-                   : (tab ? (L.unit ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab,unit>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab>") \
+                   : (tab ? (unit ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab,unit>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab>") \
                           : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"); \
     }
 #define YUV_FMT(W, X, Y) YUV_CASE(W, X, Y, 0) YUV_CASE(W, X, Y, 1) YUV_CASE(W, X, Y, 2)

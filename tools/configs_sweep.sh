@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/configs_sweep.sh -- one bench line per BASELINE.json config / format family (1 GPU), as a table.
-run() { timeout -k 10 200 python bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | python -c "
+run() { timeout -k 10 200 python bench.py --no-cpu-baseline --steps 40 --warmup 10 "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']; w=c.get('lds_window') or {}
 print('| %-62s | %9.0f | %6.0f | %5.1f%% | %s | %s |' % (c['workload'].split(', row-block')[0][:62], d['value'], r['achieved'], 100*r['frac'], c['kernel'], '%d/%d/%d' % (w.get('tiles',0), w.get('misses',0), w.get('global_tiles',0))))"; }
@@ -19,3 +19,8 @@ run --size uhd --fmt yuv444p10le --interp tetrahedral --frames 16
 run --size uhd --fmt gbrp10le --interp tetrahedral --frames 16
 run --size uhd --fmt gbrp10le --interp trilinear --frames 16
 run --size uhd --fmt gbrp --interp tetrahedral --frames 32
+run --size uhd --fmt gbrp10le --interp nearest --frames 16
+run --size uhd --fmt rgb24 --interp tetrahedral --frames 32
+run --size uhd --fmt rgba --interp tetrahedral --frames 32
+run --size uhd --fmt rgb48le --interp tetrahedral --frames 16
+run --size uhd --fmt rgba64le --interp tetrahedral --frames 16
