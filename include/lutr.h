@@ -148,6 +148,10 @@ const char *lutr_last_error(void);
  * clip(1/(DOMAIN_MAX[c]-DOMAIN_MIN[c]), 0, 1).  Free with lutr_cube_free. */
 int  lutr_cube_parse(const char *path, float **rgb, int *n, float scale[3]);
 void lutr_cube_free(float *rgb);
+/* Any 3D LUT file lut3d's file= option accepts, chosen by extension like FFmpeg does: .cube (as above),
+ * .dat, .3dl, .m3d, .csp (cineSpace without a pre-LUT shaper; a file with one is LUTR_EINVAL).  Same
+ * outputs as lutr_cube_parse; free with lutr_cube_free.  Unknown extension: LUTR_EINVAL. */
+int  lutr_lut_parse(const char *path, float **rgb, int *n, float scale[3]);
 
 /* ---- context ---- */
 int  lutr_ctx_create(int device, lutr_ctx **out);

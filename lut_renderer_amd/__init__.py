@@ -4,9 +4,9 @@ ionlz/LUT-renderer (its `lut3d` filter chain, /root/reference/src/lut_renderer/f
 Importing the package does not need a GPU; creating a `LutEngine` does.
 """
 from . import _native  # noqa: F401  (fails loudly at first use if liblutr.so is missing)
-from .cube import CubeLut, read_cube, write_cube, identity_lattice, log709_lattice  # noqa: F401
+from .cube import CubeLut, read_cube, read_lut, write_cube, identity_lattice, log709_lattice  # noqa: F401
 
-__all__ = ["CubeLut", "read_cube", "write_cube", "identity_lattice", "log709_lattice", "LutEngine"]
+__all__ = ["CubeLut", "read_cube", "read_lut", "write_cube", "identity_lattice", "log709_lattice", "LutEngine"]
 
 
 def __getattr__(name):

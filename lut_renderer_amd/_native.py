@@ -23,7 +23,7 @@ VARIANT = {"auto": 0, "generic": 1, "vec_global": 2, "vec_lds": 3}
 #: every symbol include/lutr.h declares (tests check the library exports each one)
 SYMBOLS = (
     "lutr_version", "lutr_last_error",
-    "lutr_cube_parse", "lutr_cube_free",
+    "lutr_cube_parse", "lutr_cube_free", "lutr_lut_parse",
     "lutr_ctx_create", "lutr_ctx_destroy", "lutr_ctx_set_stream", "lutr_ctx_sync",
     "lutr_ctx_set_lut", "lutr_ctx_lut_alloc", "lutr_ctx_lut_device", "lutr_ctx_lut_seal",
     "lutr_lattice_bytes",
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     lib.lutr_version.restype = cp
     lib.lutr_last_error.restype = cp
     lib.lutr_cube_parse.argtypes = [cp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(ci), C.POINTER(C.c_float)]
+    lib.lutr_lut_parse.argtypes = lib.lutr_cube_parse.argtypes
     lib.lutr_cube_free.argtypes = [C.POINTER(C.c_float)]
     lib.lutr_cube_free.restype = None
     lib.lutr_ctx_create.argtypes = [ci, C.POINTER(vp)]

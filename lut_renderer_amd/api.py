@@ -19,7 +19,7 @@ from __future__ import annotations
 from pathlib import Path
 from typing import Dict, Optional, Sequence, Tuple
 
-from .cube import CubeLut, read_cube
+from .cube import CubeLut, read_cube, read_lut
 from .params import ProcessingParams, VideoInfo, infer_bit_depth
 from .plan import LutPlan, output_color_tags, resolve_lut_plan
 
@@ -35,7 +35,7 @@ def _cached_cube(path: Path) -> CubeLut:
     key = (str(path), st.st_mtime, st.st_size)
     if key not in _lut_cache:
         _lut_cache.clear()
-        _lut_cache[key] = read_cube(path)
+        _lut_cache[key] = read_lut(path)
     return _lut_cache[key]
 
 

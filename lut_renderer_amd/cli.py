@@ -54,7 +54,7 @@ def main(argv=None) -> int:
         if os.path.exists(args.output) and not args.y:
             raise FileExistsError(f"{args.output} exists (pass -y to overwrite)")
         from .api import engine_call_for
-        from .cube import read_cube
+        from .cube import read_lut
         from .engine import LutEngine
         from .params import ProcessingParams, VideoInfo, infer_bit_depth
         from .plan import resolve_lut_plan
@@ -67,7 +67,7 @@ def main(argv=None) -> int:
         plan = resolve_lut_plan(params, args.cube, info)
         kw = engine_call_for(plan, args.pix_fmt, args.out_pix_fmt)
         eng = LutEngine(args.device)
-        eng.set_lut(read_cube(args.cube))
+        eng.set_lut(read_lut(args.cube))
         pix_fmt, out_fmt = kw.pop("pix_fmt"), kw.pop("out_pix_fmt")
         pipe = HostPipeline(eng, pix_fmt, w, h, batch=args.batch, out_pix_fmt=out_fmt, **kw)
         fb = pipe.fin.frame_bytes

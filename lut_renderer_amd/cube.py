@@ -37,11 +37,21 @@ class CubeLut:
 
 def read_cube(path) -> CubeLut:
     """Parse `path` with liblutr (FFmpeg parse_cube semantics).  Raises LutrError."""
+    return _read_with("lutr_cube_parse", path)
+
+
+def read_lut(path) -> CubeLut:
+    """Parse any 3D LUT file lut3d accepts (.cube, .dat, .3dl, .m3d, .csp without a shaper), picked by
+    extension like FFmpeg's file= option.  Raises LutrError."""
+    return _read_with("lutr_lut_parse", path)
+
+
+def _read_with(symbol: str, path) -> CubeLut:
     lib = _native.load()
     rgb = C.POINTER(C.c_float)()
     n = C.c_int(0)
     scale = (C.c_float * 3)()
-    _native.check(lib.lutr_cube_parse(str(path).encode(), C.byref(rgb), C.byref(n), scale))
+    _native.check(getattr(lib, symbol)(str(path).encode(), C.byref(rgb), C.byref(n), scale))
     try:
         count = n.value ** 3 * 3
         table = np.ctypeslib.as_array(rgb, shape=(count,)).astype(np.float32, copy=True)

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .cube import CubeLut, read_cube
+from .cube import CubeLut, read_cube, read_lut
 
 _PIXFMT_RE = re.compile(r"^(yuvj?|gbr)(420|422|444)?p(\d+)?(le)?$")
 
@@ -139,7 +139,7 @@ class LutEngine:
         self.n, self.scale = int(lut.n), np.array(lut.scale, dtype=np.float32)
 
     def load_cube(self, path) -> CubeLut:
-        lut = read_cube(path)
+        lut = read_lut(path)
         self.set_lut(lut)
         return lut
 

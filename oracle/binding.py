@@ -65,6 +65,7 @@ def load() -> C.CDLL:
         P3 = C.c_void_p * 3
         S3 = C.c_ssize_t * 3
         lib.orc_cube_parse.argtypes = [C.c_char_p, C.POINTER(OrcLut)]
+        lib.orc_lut_file_parse.argtypes = [C.c_char_p, C.POINTER(OrcLut)]
         lib.orc_lut_free.argtypes = [C.POINTER(OrcLut)]
         lib.orc_lut_free.restype = None
         lib.orc_apply_planar_rgb.argtypes = [C.POINTER(OrcLut), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -79,9 +80,18 @@ def load() -> C.CDLL:
 
 def parse_cube(path):
     """-> (n, scale float32[3], table float32[n,n,n,3]); raises OracleError(code)."""
+    return _parse_with("orc_cube_parse", path)
+
+
+def parse_lut_file(path):
+    """Any lut3d file format by extension (.cube .dat .3dl .m3d .csp); same return as parse_cube."""
+    return _parse_with("orc_lut_file_parse", path)
+
+
+def _parse_with(symbol, path):
     lib = load()
     lut = OrcLut()
-    rc = lib.orc_cube_parse(str(path).encode(), C.byref(lut))
+    rc = getattr(lib, symbol)(str(path).encode(), C.byref(lut))
     if rc:
         raise OracleError(rc)
     try:

@@ -154,6 +154,212 @@ void orc_lut_free(orc_lut *lut)
 }
 
 /* ------------------------------------------------------------------ */
+/* the other lut3d file formats [FFmpeg-recall:   */
+/* vf_lut3d.c parse_dat / parse_3dl / parse_m3d / parse_cinespace]      */
+/* ------------------------------------------------------------------ */
+
+/* NEXT_LINE(loop_cond): read lines while loop_cond holds; EOF -> "Unexpected EOF", invalid data */
+#define NEXT_LINE(loop_cond) do {                         \
+        if (!fgets(line, sizeof(line), f)) { rc = ORC_EILSEQ; goto done; } \
+    } while (loop_cond)
+
+static int alloc_lut(orc_lut *out, int size)
+{
+    if (size < 2 || size > MAX_LEVEL)        /* allocate_3dlut: "Too large or invalid 3D LUT size" */
+        return ORC_EINVAL;
+    out->n = size;
+    out->rgb = (float *)malloc((size_t)size * size * size * 3 * sizeof(float));
+    return out->rgb ? 0 : ORC_ENOMEM;
+}
+
+static int parse_dat(FILE *f, orc_lut *out)
+{
+    char line[MAX_LINE_SIZE];
+    int rc = 0, i, j, k, size = 33;
+    NEXT_LINE(skip_line(line));
+    if (!strncmp(line, "3DLUTSIZE ", 10)) {
+        size = (int)strtol(line + 10, NULL, 0);
+        NEXT_LINE(skip_line(line));
+    }
+    if ((rc = alloc_lut(out, size)))
+        goto done;
+    for (k = 0; k < size; k++)
+        for (j = 0; j < size; j++)
+            for (i = 0; i < size; i++) {
+                float *vec = &out->rgb[(((size_t)k * size + j) * size + i) * 3];
+                if (k != 0 || j != 0 || i != 0)
+                    NEXT_LINE(skip_line(line));
+                if (sscanf(line, "%f %f %f", &vec[0], &vec[1], &vec[2]) != 3) { rc = ORC_EILSEQ; goto done; }
+            }
+done:
+    return rc;
+}
+
+static int parse_3dl(FILE *f, orc_lut *out)
+{
+    char line[MAX_LINE_SIZE];
+    int rc, i, j, k;
+    const int size = 17;
+    const float scale = 16 * 16 * 16;
+    if ((rc = alloc_lut(out, size)))
+        goto done;
+    NEXT_LINE(skip_line(line));
+    for (k = 0; k < size; k++)
+        for (j = 0; j < size; j++)
+            for (i = 0; i < size; i++) {
+                int r, g, b;
+                float *vec = &out->rgb[(((size_t)k * size + j) * size + i) * 3];
+                NEXT_LINE(skip_line(line));
+                if (sscanf(line, "%d %d %d", &r, &g, &b) != 3) { rc = ORC_EILSEQ; goto done; }
+                vec[0] = r / scale;
+                vec[1] = g / scale;
+                vec[2] = b / scale;
+            }
+done:
+    return rc;
+}
+
+static int parse_m3d(FILE *f, orc_lut *out)
+{
+    float scale;
+    int rc = 0, i, j, k, size, in = -1, outv = -1;
+    char line[MAX_LINE_SIZE];
+    unsigned char rgb_map[3] = {0, 1, 2};
+
+    while (fgets(line, sizeof(line), f)) {
+        if (!strncmp(line, "in", 2)) in = (int)strtol(line + 2, NULL, 0);
+        else if (!strncmp(line, "out", 3)) outv = (int)strtol(line + 3, NULL, 0);
+        else if (!strncmp(line, "values", 6)) {
+            const char *p = line + 6;
+            for (int id = 0; id < 3; id++) {
+                while (isspace((unsigned char)*p)) p++;
+                switch (*p) {
+                case 'r': rgb_map[id] = 0; break;
+                case 'g': rgb_map[id] = 1; break;
+                case 'b': rgb_map[id] = 2; break;
+                }
+                while (*p && !isspace((unsigned char)*p)) p++;
+            }
+            break;
+        }
+    }
+    if (in == -1 || outv == -1)
+        return ORC_EILSEQ;
+    if (in < 2 || outv < 2 || in > MAX_LEVEL * MAX_LEVEL * MAX_LEVEL || outv > MAX_LEVEL * MAX_LEVEL * MAX_LEVEL)
+        return ORC_EILSEQ;
+    for (size = 1; size * size * size < in; size++)
+        ;
+    if ((rc = alloc_lut(out, size)))
+        goto done;
+    scale = 1. / (outv - 1);
+    for (k = 0; k < size; k++)
+        for (j = 0; j < size; j++)
+            for (i = 0; i < size; i++) {
+                float *vec = &out->rgb[(((size_t)k * size + j) * size + i) * 3];
+                float val[3];
+                NEXT_LINE(0);
+                if (sscanf(line, "%f %f %f", val, val + 1, val + 2) != 3) { rc = ORC_EILSEQ; goto done; }
+                vec[0] = val[rgb_map[0]] * scale;
+                vec[1] = val[rgb_map[1]] * scale;
+                vec[2] = val[rgb_map[2]] * scale;
+            }
+done:
+    return rc;
+}
+
+/* cineSpace .csp, the branch without a pre-LUT (2 points per channel = input / output ranges).  A file
+ * with a real shaper (npoints > 2) needs lut3d's prelut stage, which this engine does not have: EINVAL. */
+static int parse_cinespace(FILE *f, orc_lut *out)
+{
+    char line[MAX_LINE_SIZE];
+    float in_min[3] = {0.0f, 0.0f, 0.0f}, in_max[3] = {1.0f, 1.0f, 1.0f};
+    float out_min[3] = {0.0f, 0.0f, 0.0f}, out_max[3] = {1.0f, 1.0f, 1.0f};
+    int inside_metadata = 0, size, rc = 0;
+
+    NEXT_LINE(skip_line(line));
+    if (strncmp(line, "CSPLUTV100", 10)) return ORC_EINVAL;
+    NEXT_LINE(skip_line(line));
+    if (strncmp(line, "3D", 2)) return ORC_EINVAL;
+    while (1) {
+        NEXT_LINE(skip_line(line));
+        if (!strncmp(line, "BEGIN METADATA", 14)) { inside_metadata = 1; continue; }
+        if (!strncmp(line, "END METADATA", 12)) { inside_metadata = 0; continue; }
+        if (inside_metadata == 0) {
+            int size_r, size_g, size_b;
+            for (int i = 0; i < 3; i++) {
+                int npoints = (int)strtol(line, NULL, 0);
+                if (npoints > 2) return ORC_EINVAL;                 /* shaper: unsupported here */
+                if (npoints != 2) return ORC_EILSEQ;
+                NEXT_LINE(skip_line(line));
+                if (sscanf(line, "%f %f", &in_min[i], &in_max[i]) != 2) return ORC_EILSEQ;
+                NEXT_LINE(skip_line(line));
+                if (sscanf(line, "%f %f", &out_min[i], &out_max[i]) != 2) return ORC_EILSEQ;
+                NEXT_LINE(skip_line(line));
+            }
+            if (sscanf(line, "%d %d %d", &size_r, &size_g, &size_b) != 3) return ORC_EILSEQ;
+            if (size_r != size_g || size_r != size_b) return ORC_EILSEQ;
+            size = size_r;
+            if ((rc = alloc_lut(out, size)))
+                goto done;
+            for (int k = 0; k < size; k++)
+                for (int j = 0; j < size; j++)
+                    for (int i = 0; i < size; i++) {
+                        float *vec = &out->rgb[(((size_t)i * size + j) * size + k) * 3];
+                        NEXT_LINE(skip_line(line));
+                        if (sscanf(line, "%f %f %f", &vec[0], &vec[1], &vec[2]) != 3) { rc = ORC_EILSEQ; goto done; }
+                        vec[0] *= out_max[0] - out_min[0];
+                        vec[1] *= out_max[1] - out_min[1];
+                        vec[2] *= out_max[2] - out_min[2];
+                    }
+            break;
+        }
+    }
+    for (int c = 0; c < 3; c++) {
+        float s = (float)(1. / (in_max[c] - in_min[c]));
+        if (s < 0.f) s = 0.f;
+        if (s > 1.f) s = 1.f;
+        if (s != s) s = 0.f;
+        out->scale[c] = s;
+    }
+done:
+    return rc;
+}
+
+/* lut3d's config: the parser is chosen by the (case-insensitive) extension; none / unknown -> EINVAL */
+int orc_lut_file_parse(const char *path, orc_lut *out)
+{
+    const char *ext;
+    char e[8] = {0};
+    FILE *f;
+    int rc;
+    if (!path || !out)
+        return ORC_EINVAL;
+    ext = strrchr(path, '.');
+    if (!ext)
+        return ORC_EINVAL;
+    ext++;
+    for (int i = 0; i < 7 && ext[i]; i++)
+        e[i] = (char)tolower((unsigned char)ext[i]);
+    if (!strcmp(e, "cube"))
+        return orc_cube_parse(path, out);
+    if (strcmp(e, "dat") && strcmp(e, "3dl") && strcmp(e, "m3d") && strcmp(e, "csp"))
+        return ORC_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->scale[0] = out->scale[1] = out->scale[2] = 1.0f;
+    f = fopen(path, "r");
+    if (!f)
+        return ORC_ENOENT;
+    if (!strcmp(e, "dat")) rc = parse_dat(f, out);
+    else if (!strcmp(e, "3dl")) rc = parse_3dl(f, out);
+    else if (!strcmp(e, "m3d")) rc = parse_m3d(f, out);
+    else rc = parse_cinespace(f, out);
+    fclose(f);
+    if (rc)
+        orc_lut_free(out);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
 /* interpolation: SURVEY.md A.4 / A.5 (vf_lut3d.c interp_*)            */
 /* ------------------------------------------------------------------ */
 

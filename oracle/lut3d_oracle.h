@@ -44,6 +44,8 @@ typedef struct orc_lut {
 } orc_lut;
 
 int  orc_cube_parse(const char *path, orc_lut *out);
+/* any file lut3d reads (.cube .dat .3dl .m3d .csp-without-shaper), by extension */
+int  orc_lut_file_parse(const char *path, orc_lut *out);
 void orc_lut_free(orc_lut *lut);
 
 /* Planar RGB, FFmpeg gbrp plane order: plane 0 = G, 1 = B, 2 = R.

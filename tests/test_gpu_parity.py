@@ -457,3 +457,27 @@ def test_seal_records_range_and_rejects_non_finite(cube_dir):
         with pytest.raises(_native.LutrError) as ei:
             _native.check(b._lib.lutr_ctx_lut_seal(b._ctx))
         assert ei.value.code == _native.EINVAL
+
+
+def test_non_cube_lut_files_end_to_end(engine, orc, tmp_path):
+    """a .3dl and a .dat file through the product reader and the kernels, against the
+    oracle's reader and pixel path."""
+    rng = np.random.default_rng(12)
+    codes = np.sort(rng.integers(0, 4096, size=(17, 17, 17, 3)), axis=0)
+    p3 = tmp_path / "look.3dl"
+    p3.write_text(" ".join(str(min(64 * i, 1023)) for i in range(17)) + "\n" +
+                  "".join("%d %d %d\n" % tuple(codes[r, g, b]) for r in range(17) for g in range(17) for b in range(17)))
+    tab = cube.log709_lattice(9)
+    pd = tmp_path / "look.dat"
+    pd.write_text("3DLUTSIZE 9\n" + "".join("%.7f %.7f %.7f\n" % tuple(tab[r, g, b]) for r in range(9)
+                                             for g in range(9) for b in range(9)))
+    src = frames.natural_yuv(256, 64, 10, 1, 1, k=2)
+    k = orc.yuv_constants(din=10)
+    for path in (p3, pd):
+        lut = engine.load_cube(path)
+        n, scale, table = orc.parse_lut_file(path)
+        assert lut.n == n and np.array_equal(lut.table, table)
+        for mode in ("tetrahedral", "trilinear"):
+            got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le", interp=mode)
+            _assert_equal(_to_np(got, np.uint16), orc.apply_yuv(table, scale, mode, k, 10, 10, 10, 1, 1, src),
+                          f"{path.suffix} {mode}")

@@ -1,0 +1,147 @@
+"""The other 3D LUT files lut3d reads: .dat, .3dl, .m3d, .csp.
+
+Two independently written readers -- the product's (liblutr `lutr_lut_parse`, a record scanner) and the
+oracle's (FFmpeg's loops restated in C) -- must produce identical lattices from the same files, and both
+must match hand-computed known answers.  The reference's GUI only offers *.cube (lut_manager.py:121);
+FFmpeg's `lut3d=file=` (ffmpeg.py:246) picks the parser from the extension, and so does the engine.
+"""
+import numpy as np
+import pytest
+
+from lut_renderer_amd import _native, cube
+
+
+def _both(orc, path):
+    n, scale, table = orc.parse_lut_file(path)
+    lut = cube.read_lut(path)
+    assert lut.n == n
+    assert np.array_equal(lut.scale, scale)
+    assert np.array_equal(lut.table.view(np.uint32), table.view(np.uint32))     # bit for bit
+    return lut
+
+
+def _rows_blue_fastest(tab):
+    n = tab.shape[0]
+    return [tab[r, g, b] for r in range(n) for g in range(n) for b in range(n)]
+
+
+def _rows_red_fastest(tab):
+    n = tab.shape[0]
+    return [tab[r, g, b] for b in range(n) for g in range(n) for r in range(n)]
+
+
+def test_dat_default_size_is_33_and_blue_varies_fastest(orc, tmp_path):
+    tab = cube.log709_lattice(33)
+    p = tmp_path / "look.dat"
+    p.write_text("# comment\n\n" + "".join("%.6f %.6f %.6f\n" % tuple(v) for v in _rows_blue_fastest(tab)))
+    lut = _both(orc, p)
+    assert lut.n == 33 and np.array_equal(lut.scale, np.ones(3, np.float32))
+    want = np.array(["%.6f" % v for v in tab.ravel()], dtype=np.float64).astype(np.float32).reshape(tab.shape)
+    assert np.array_equal(lut.table, want)
+
+
+def test_dat_with_explicit_size(orc, tmp_path):
+    rng = np.random.default_rng(3)
+    tab = rng.random((5, 5, 5, 3)).astype(np.float32)
+    p = tmp_path / "small.DAT"                                    # extension match is case-insensitive
+    p.write_text("3DLUTSIZE 5\n# c\n" + "".join("%.9g %.9g %.9g\n" % tuple(v) for v in _rows_blue_fastest(tab)))
+    assert np.array_equal(_both(orc, p).table, tab)
+    (tmp_path / "bad.dat").write_text("3DLUTSIZE 300\n0 0 0\n")
+    with pytest.raises(_native.LutrError) as ei:
+        cube.read_lut(tmp_path / "bad.dat")
+    assert ei.value.code == _native.EINVAL
+    with pytest.raises(orc.OracleError):
+        orc.parse_lut_file(tmp_path / "bad.dat")
+    (tmp_path / "short.dat").write_text("3DLUTSIZE 2\n0 0 0\n1 1 1\n")
+    with pytest.raises(_native.LutrError) as ei:
+        cube.read_lut(tmp_path / "short.dat")
+    assert ei.value.code == _native.EILSEQ
+
+
+def test_3dl_is_17_cubed_twelve_bit_integers(orc, tmp_path):
+    rng = np.random.default_rng(4)
+    codes = rng.integers(0, 4096, size=(17, 17, 17, 3))
+    p = tmp_path / "lustre.3dl"
+    shaper = " ".join(str(min(64 * i, 1023)) for i in range(17))
+    p.write_text("# header\n" + shaper + "\n" + "".join("%d %d %d\n" % tuple(v) for v in _rows_blue_fastest(codes)))
+    lut = _both(orc, p)
+    assert lut.n == 17
+    assert np.array_equal(lut.table, (codes / 4096.0).astype(np.float32))        # exact: 12-bit / 2^12
+    assert lut.table[16, 0, 3, 1] == np.float32(codes[16, 0, 3, 1] / 4096.0)
+
+
+def test_m3d_column_order_and_out_scale(orc, tmp_path):
+    rng = np.random.default_rng(5)
+    n, out = 4, 1024
+    vals = rng.integers(0, out, size=(n, n, n, 3))
+    p = tmp_path / "pandora.m3d"
+    head = "name x\nin %d\nout %d\nformat lut\nvalues\tblue\tgreen\tred\n" % (n ** 3, out)
+    # columns are written blue, green, red: the reader maps them back to r, g, b
+    p.write_text(head + "".join("%d %d %d\n" % (v[2], v[1], v[0]) for v in _rows_blue_fastest(vals)))
+    lut = _both(orc, p)
+    assert lut.n == n
+    k = np.float32(1.0 / (out - 1))
+    assert np.array_equal(lut.table, vals.astype(np.float32) * k)
+    (tmp_path / "noin.m3d").write_text("out 10\nvalues r g b\n0 0 0\n")
+    with pytest.raises(_native.LutrError) as ei:
+        cube.read_lut(tmp_path / "noin.m3d")
+    assert ei.value.code == _native.EILSEQ
+    with pytest.raises(orc.OracleError):
+        orc.parse_lut_file(tmp_path / "noin.m3d")
+
+
+def test_m3d_size_is_the_cube_root_rounded_up(orc, tmp_path):
+    p = tmp_path / "odd.m3d"                                       # in = 9 -> size 3 (27 rows are read)
+    p.write_text("in 9\nout 2\nvalues r g b\n" + "1 0 1\n" * 27)
+    lut = _both(orc, p)
+    assert lut.n == 3 and np.array_equal(lut.table[..., 1], np.zeros((3, 3, 3), np.float32))
+
+
+def test_csp_ranges_metadata_and_red_fastest_order(orc, tmp_path):
+    rng = np.random.default_rng(6)
+    n = 3
+    tab = rng.random((n, n, n, 3)).astype(np.float32)
+    p = tmp_path / "cine.csp"
+    text = ("CSPLUTV100\n3D\n\nBEGIN METADATA\nanything 3 4 5\nEND METADATA\n\n"
+            "2\n0.0 2.0\n0.0 1.0\n\n2\n0.0 1.0\n0.0 0.5\n\n2\n0.0 4.0\n0.25 1.0\n\n"
+            "%d %d %d\n" % (n, n, n) + "".join("%.9g %.9g %.9g\n" % tuple(v) for v in _rows_red_fastest(tab)))
+    p.write_text(text)
+    lut = _both(orc, p)
+    assert np.array_equal(lut.scale, np.array([0.5, 1.0, 0.25], np.float32))     # clip(1/(in_max-in_min), 0, 1)
+    want = tab * np.array([1.0, 0.5, 0.75], np.float32)                          # * (out_max - out_min)
+    assert np.array_equal(lut.table, want)
+    # a real pre-LUT shaper is refused by both readers
+    p2 = tmp_path / "shaper.csp"
+    p2.write_text("CSPLUTV100\n3D\n\n3\n0.0 0.5 1.0\n0.0 0.4 1.0\n" + text.split("END METADATA\n\n", 1)[1])
+    with pytest.raises(_native.LutrError) as ei:
+        cube.read_lut(p2)
+    assert ei.value.code == _native.EINVAL and "pre-LUT" in ei.value.message
+    with pytest.raises(orc.OracleError):
+        orc.parse_lut_file(p2)
+    (tmp_path / "wrong.csp").write_text("CSPLUTV100\n1D\n")
+    with pytest.raises(_native.LutrError):
+        cube.read_lut(tmp_path / "wrong.csp")
+
+
+def test_extension_picks_the_reader(orc, tmp_path, cube_dir):
+    a = cube.read_lut(cube_dir / "log709_33.cube")
+    b = cube.read_cube(cube_dir / "log709_33.cube")
+    assert a.n == b.n and np.array_equal(a.table, b.table) and np.array_equal(a.scale, b.scale)
+    for name in ("look.txt", "noext", "look.cube.bak"):
+        q = tmp_path / name
+        q.write_text("LUT_3D_SIZE 2\n" + "0 0 0\n" * 8)
+        with pytest.raises(_native.LutrError) as ei:
+            cube.read_lut(q)
+        assert ei.value.code == _native.EINVAL
+        with pytest.raises(orc.OracleError):
+            orc.parse_lut_file(q)
+    with pytest.raises(_native.LutrError) as ei:
+        cube.read_lut(tmp_path / "missing.3dl")
+    assert ei.value.code == _native.ENOENT
+
+
+def test_non_finite_entries_are_rejected_by_the_product(tmp_path):
+    (tmp_path / "nan.dat").write_text("3DLUTSIZE 2\n" + "0 0 0\n" * 7 + "nan 0 0\n")
+    with pytest.raises(_native.LutrError) as ei:
+        cube.read_lut(tmp_path / "nan.dat")
+    assert ei.value.code == _native.EILSEQ
