@@ -68,10 +68,18 @@ def dist_setup(gpus: int):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs (tests/test_gpu_parity.py): run the N-rank control flow on a box with fewer GPUs by
+    # putting every rank on one device and moving the collectives to gloo.  Never set by the driver.
+    backend = os.environ.get("LUTR_DIST_BACKEND", "nccl")
+    if "LUTR_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["LUTR_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
         assert dist.get_world_size() == gpus, f"--gpus {gpus} but WORLD_SIZE {world}"
     elif gpus != 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")

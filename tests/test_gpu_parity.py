@@ -481,3 +481,54 @@ def test_non_cube_lut_files_end_to_end(engine, orc, tmp_path):
             got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le", interp=mode)
             _assert_equal(_to_np(got, np.uint16), orc.apply_yuv(table, scale, mode, k, 10, 10, 10, 1, 1, src),
                           f"{path.suffix} {mode}")
+
+
+def _torchrun(nproc, script_args, extra_env, timeout=300):
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LUTR_DIST_BACKEND="gloo", LUTR_FORCE_DEVICE="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_rank_lut_broadcast_and_row_blocks(orc, cube_dir, tmp_path):
+    """The N>1 control flow with two ranks sharing the one GPU of the test box (collective over gloo): the
+    receiving rank's alloc -> broadcast -> seal path and per-rank row blocks against the whole-frame oracle."""
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    res = _torchrun(2, [str(root / "tests" / "_gpu_dist_worker.py"), str(tmp_path), str(cube_dir / "log709_33.cube")], {})
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    src = frames.natural_yuv(256, 72, 10, 1, 1, k=9)
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", orc.yuv_constants(din=10), 10, 10, 10, 1, 1, src)
+    rows = 0
+    for rank in range(2):
+        d = np.load(tmp_path / f"rank{rank}.npz")
+        r0, r1 = int(d["r0"]), int(d["r1"])
+        rows += r1 - r0
+        assert "unit" in str(d["kernel"])                      # the received lattice was sealed on rank 1 too
+        assert np.array_equal(d["y"][r0:r1], want[0][r0:r1])
+        assert np.array_equal(d["cb"][r0 // 2:r1 // 2], want[1][r0 // 2:r1 // 2])
+        assert np.array_equal(d["cr"][r0 // 2:r1 // 2], want[2][r0 // 2:r1 // 2])
+    assert rows == 72
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N>1 path end to end (torchrun, barriers, max/sum reductions, one JSON line from rank 0)."""
+    import json
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    res = _torchrun(2, [str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "2",
+                        "--size", "1080p"], {})
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["config"]["parallelism"] == "row-block x2" and "tile" in d["config"]["kernel"]
