@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--no-stats", action="store_true", help="skip the extra LDS-window statistics pass (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--extra", action="store_true", help="also time the other distribution / mode (stderr only)")
+    ap.add_argument("--dither", default="none", choices=["none", "error_diffusion"],
+                    help="also dither the final quantisation (reference option zscale_dither; YUV formats, informational)")
     ap.add_argument("--pipeline", default="hbm", choices=["hbm", "host"],
                     help="host: also time BASELINE config 5 (frames in pinned host memory, overlapped copies); "
                          "reported as `host_pipeline`, never as `value`")
@@ -92,7 +94,12 @@ def barrier(world):
         dist.barrier()
 
 
+DITHER = "none"
+
+
 def apply(eng, pf, src, dst, fmt, interp):
+    if DITHER != "none":
+        return eng.apply_yuv(src, dst, pix_fmt=fmt, interp=interp, dither=DITHER)
     if pf.family == "packed":
         return eng.apply_packed(src[0], dst[0], pix_fmt=fmt, interp=interp)
     if pf.family == "gbr":
@@ -194,6 +201,8 @@ def load_traffic(tag):
 
 def main():
     args = parse_args()
+    global DITHER
+    DITHER = args.dither
     rank, local, world = dist_setup(args.gpus)
     from lut_renderer_amd import cube
     from lut_renderer_amd.engine import LutEngine, parse_pix_fmt
@@ -306,6 +315,7 @@ def main():
                             f"{args.frames} frames/GPU/step resident in HBM, row-block shard x{world}",
                 "frames_per_gpu": args.frames, "lut_size": args.lut, "interp": args.interp,
                 "pix_fmt": args.fmt, "distribution": args.dist, "kernel": kernel_name, "lds_window": tile_stats,
+                "dither": args.dither,
                 "parallelism": f"row-block x{world}", "bytes_per_pixel": bpp,
             },
             "roofline": {

@@ -193,6 +193,16 @@ int lutr_apply_packed_rgb(lutr_ctx *ctx, int pfmt, int interp, int w, int h, int
 int lutr_apply_yuv(lutr_ctx *ctx, const lutr_yuv_params *p, int interp, int w, int h, int nframes,
                    const lutr_planes *src, const lutr_planes *dst, int row0, int rows);
 
+/* zscale_dither of the reference (models.py:46; the filter `zscale=dither=error_diffusion`, ffmpeg.py:305-307) */
+enum lutr_dither { LUTR_DITHER_NONE = 0, LUTR_DITHER_ERROR_DIFFUSION = 1 };
+
+/* lutr_apply_yuv with the final quantisation dithered: Floyd-Steinberg error diffusion per output plane
+ * (rows top to bottom, left to right).  Rows are coupled, so this takes whole frames only;
+ * shard a batch over GPUs by frames.  dither == LUTR_DITHER_NONE is lutr_apply_yuv on rows [0, h).
+ * Uses context-owned device scratch of 4 bytes per output sample of the batch. */
+int lutr_apply_yuv_dither(lutr_ctx *ctx, const lutr_yuv_params *p, int interp, int dither, int w, int h, int nframes,
+                          const lutr_planes *src, const lutr_planes *dst);
+
 /* ---- tuning / introspection (bench and tests) ---- */
 /* kernel variant: 0 = auto, 1 = generic (scalar, any layout), 2 = vector + global gather,
  * 3 = vector + LDS lattice window */

@@ -18,6 +18,7 @@ OK, ENOENT, EIO, ENOMEM, EINVAL, EILSEQ = 0, -2, -5, -12, -22, -84
 INTERP = {"nearest": 0, "trilinear": 1, "tetrahedral": 2, "pyramid": 3, "prism": 4}
 MATRIX = {"bt709": 0, "smpte170m": 1, "bt470bg": 1, "bt601": 1, "bt2020nc": 2, "bt2020c": 2}
 RANGE = {"tv": 0, "pc": 1}
+DITHER = {"none": 0, "error_diffusion": 1}
 VARIANT = {"auto": 0, "generic": 1, "vec_global": 2, "vec_lds": 3}
 
 #: every symbol include/lutr.h declares (tests check the library exports each one)
@@ -27,7 +28,7 @@ SYMBOLS = (
     "lutr_ctx_create", "lutr_ctx_destroy", "lutr_ctx_set_stream", "lutr_ctx_sync",
     "lutr_ctx_set_lut", "lutr_ctx_lut_alloc", "lutr_ctx_lut_device", "lutr_ctx_lut_seal",
     "lutr_lattice_bytes",
-    "lutr_apply_planar_rgb", "lutr_apply_packed_rgb", "lutr_apply_yuv",
+    "lutr_apply_planar_rgb", "lutr_apply_packed_rgb", "lutr_apply_yuv", "lutr_apply_yuv_dither",
     "lutr_ctx_set_variant", "lutr_ctx_last_kernel", "lutr_ctx_tile_stats", "lutr_yuv_constants",
 )
 
@@ -111,6 +112,8 @@ def load() -> C.CDLL:
     lib.lutr_apply_packed_rgb.argtypes = [vp, ci, ci, ci, ci, ci, C.POINTER(Packed), C.POINTER(Packed), ci, ci]
     lib.lutr_apply_yuv.argtypes = [vp, C.POINTER(YuvParams), ci, ci, ci, ci, C.POINTER(Planes), C.POINTER(Planes),
                                    ci, ci]
+    lib.lutr_apply_yuv_dither.argtypes = [vp, C.POINTER(YuvParams), ci, ci, ci, ci, ci, C.POINTER(Planes),
+                                          C.POINTER(Planes)]
     lib.lutr_ctx_set_variant.argtypes = [vp, ci]
     lib.lutr_ctx_last_kernel.argtypes = [vp]
     lib.lutr_ctx_last_kernel.restype = cp

@@ -7,6 +7,7 @@ task_manager.py:145-151), this applies the same chain to frames already resident
     [scale=in_range=pc:out_range=R, format=<8-bit>]   full-range sources only
     (auto) YUV -> RGB at the negotiated depth          matrix from lut_input_matrix / colorspace
     lut3d=file=<cube>:interp=<mode>
+    [zscale=dither=error_diffusion]                    option zscale_dither: the output quantisation is dithered
     [format=<pix_fmt>]                                 RGB -> YUV at the output depth
 
 Options use the names and values of `ProcessingParams` (models.py:45-56) and `VideoInfo`
@@ -64,7 +65,8 @@ def engine_call_for(plan: LutPlan, pix_fmt: str, out_pix_fmt: Optional[str] = No
 def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: str, width: Optional[int] = None,
               height: Optional[int] = None, input_matrix: str = "auto", colorspace: Optional[str] = None,
               color_range: Optional[str] = None, output_tags: str = "bt709", out_pix_fmt: Optional[str] = None,
-              out: Optional[Sequence] = None, engine=None, devices: Sequence[int] = (0,)):
+              zscale_dither: str = "none", out: Optional[Sequence] = None, engine=None,
+              devices: Sequence[int] = (0,)):
     """Apply `cube` to planar YUV frames on the GPU.  `planes` = (Y, Cb, Cr) torch tensors on the
     engine's device, each [H,W] or [F,H,W].  Returns (planes_out, tags) where `tags` is the colour
     metadata the reference would write for this policy (None = inherit / none).
@@ -74,11 +76,14 @@ def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: s
     from .engine import LutEngine
     if width is not None and planes[0].shape[-1] != width or height is not None and planes[0].shape[-2] != height:
         raise ValueError("plane shape does not match width/height")
-    params = ProcessingParams(lut_interp=interp, lut_input_matrix=input_matrix, lut_output_tags=output_tags)
+    params = ProcessingParams(lut_interp=interp, lut_input_matrix=input_matrix, lut_output_tags=output_tags,
+                              zscale_dither=zscale_dither)
     info = VideoInfo(width=width, height=height, pix_fmt=pix_fmt, bit_depth=infer_bit_depth(pix_fmt),
                      colorspace=colorspace, color_range=color_range)
     plan = resolve_lut_plan(params, cube if cube is not None else "engine.cube", info)
     kw = engine_call_for(plan, pix_fmt, out_pix_fmt)
+    # ffmpeg.py:305-307: any value other than "error_diffusion" leaves the chain without a dither filter
+    kw["dither"] = "error_diffusion" if getattr(params, "zscale_dither", "none") == "error_diffusion" else "none"
     own = engine is None
     eng = engine or LutEngine(devices[0])
     try:

@@ -39,6 +39,7 @@ def main(argv=None) -> int:
     ap.add_argument("--interp", default="tetrahedral")
     ap.add_argument("--input-matrix", default="auto")
     ap.add_argument("--output-tags", default="bt709")
+    ap.add_argument("--zscale-dither", default="none", help="none | error_diffusion (models.py:46)")
     ap.add_argument("--colorspace", default=None)
     ap.add_argument("--color-range", default=None)
     ap.add_argument("--fps", type=float, default=25.0)
@@ -61,11 +62,13 @@ def main(argv=None) -> int:
         from .stream import HostPipeline
 
         params = ProcessingParams(lut_interp=args.interp, lut_input_matrix=args.input_matrix,
-                                  lut_output_tags=args.output_tags)
+                                  lut_output_tags=args.output_tags, zscale_dither=args.zscale_dither)
         info = VideoInfo(width=w, height=h, pix_fmt=args.pix_fmt, bit_depth=infer_bit_depth(args.pix_fmt),
                          colorspace=args.colorspace, color_range=args.color_range)
         plan = resolve_lut_plan(params, args.cube, info)
         kw = engine_call_for(plan, args.pix_fmt, args.out_pix_fmt)
+        if args.zscale_dither == "error_diffusion":
+            kw["dither"] = "error_diffusion"
         eng = LutEngine(args.device)
         eng.set_lut(read_lut(args.cube))
         pix_fmt, out_fmt = kw.pop("pix_fmt"), kw.pop("out_pix_fmt")

@@ -166,6 +166,8 @@ struct lutr_ctx {
     std::string last_kernel;
     bool unit = false;               // every lattice node known to lie in [0, 1]
     unsigned *queue = nullptr;       // work-queue counter of the tile kernels (device), zeroed per launch
+    float *fscratch = nullptr;       // float planes of the dither path
+    size_t fscratch_floats = 0;
     unsigned *stats = nullptr;       // 8 device counters (4 reported + clock stamps), see lutr_ctx_tile_stats
 };
 
@@ -237,6 +239,7 @@ void lutr_ctx_destroy(lutr_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->lat) (void)hipFree(c->lat);
     if (c->stats) (void)hipFree(c->stats);
+    if (c->fscratch) (void)hipFree(c->fscratch);
     if (c->queue) (void)hipFree(c->queue);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -516,6 +519,43 @@ int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int
     fill_planes(&P, src, dst);
     return finish_launch(c, launch_yuv(c->stream, c->variant, L, K, P, G, LUTR_FMT_DEPTH(p->fmt_in),
                                        LUTR_FMT_DEPTH(p->fmt_out), csx, csy, interp, c->stats, c->queue));
+}
+
+int lutr_apply_yuv_dither(lutr_ctx *c, const lutr_yuv_params *p, int interp, int dither, int w, int h, int nframes,
+                          const lutr_planes *src, const lutr_planes *dst)
+{
+    if (dither == LUTR_DITHER_NONE) return lutr_apply_yuv(c, p, interp, w, h, nframes, src, dst, 0, h);
+    if (dither != LUTR_DITHER_ERROR_DIFFUSION) { set_error("unknown dither mode %d", dither); return LUTR_EINVAL; }
+    int rc = check_common(c, interp, w, h, nframes, src, dst, 0, h);
+    if (rc) return rc;
+    if (!p) { set_error("null yuv params"); return LUTR_EINVAL; }
+    YuvConsts K;
+    rc = make_yuv_consts(*p, &K);
+    if (rc) return rc;
+    if (w == 0 || h == 0 || nframes == 0) return LUTR_OK;
+    for (int i = 0; i < 3; i++)
+        if (!src->data[i] || !dst->data[i]) { set_error("null plane %d", i); return LUTR_EINVAL; }
+    const int csx = LUTR_FMT_CSX(p->fmt_in), csy = LUTR_FMT_CSY(p->fmt_in);
+    const size_t cw = (size_t)((w + (1 << csx) - 1) >> csx), ch = (size_t)((h + (1 << csy) - 1) >> csy);
+    const size_t ny = (size_t)w * h * nframes, nc = cw * ch * nframes;
+    HIP_TRY(hipSetDevice(c->device));
+    if (ny + 2 * nc > c->fscratch_floats) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->fscratch) (void)hipFree(c->fscratch);
+        c->fscratch = nullptr;
+        c->fscratch_floats = 0;
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, (ny + 2 * nc) * sizeof(float));
+        if (e != hipSuccess) { set_error("hipMalloc(%zu): %s", (ny + 2 * nc) * sizeof(float), hipGetErrorString(e)); return LUTR_ENOMEM; }
+        c->fscratch = (float *)q;
+        c->fscratch_floats = ny + 2 * nc;
+    }
+    LutConsts L; PlaneSet P; FrameGeom G{w, h, 0, h, nframes};
+    fill_lut(&L, c, p->lut_depth);
+    fill_planes(&P, src, dst);
+    FloatPlanes F{c->fscratch, c->fscratch + ny, c->fscratch + ny + nc};
+    return finish_launch(c, launch_yuv_dither(c->stream, L, K, P, G, F, LUTR_FMT_DEPTH(p->fmt_in),
+                                              LUTR_FMT_DEPTH(p->fmt_out), csx, csy, interp));
 }
 
 }  // extern "C"

@@ -52,6 +52,11 @@ struct PackedSet {
     int ro, go, bo, ao;              // ao = the fourth slot of 4-component formats (alpha or padding)
 };
 
+// unquantised output planes of the dither path (device scratch, densely packed per frame)
+struct FloatPlanes {
+    float *y, *cb, *cr;
+};
+
 struct FrameGeom {
     int w, h, row0, rows, nframes;
 };
@@ -69,6 +74,10 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
 // packed RGB (lutr_packed.hip)
 const char *launch_packed(hipStream_t st, int variant, const LutConsts &L, const PackedSet &P, const FrameGeom &G,
                           int wide, int ncomp, int interp);
+
+// error-diffusion dither path (lutr_dither.hip): whole frames, float planes in F
+const char *launch_yuv_dither(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
+                              const FrameGeom &G, const FloatPlanes &F, int din, int dout, int csx, int csy, int interp);
 
 // persistent LDS-window kernels (lutr_tile.hip); layout already checked by launch_rgb/launch_yuv
 const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G,

@@ -250,8 +250,11 @@ class LutEngine:
                   pix_fmt: str, interp: str = "tetrahedral", matrix_in: str = "bt709",
                   matrix_out: Optional[str] = None, range_src: str = "tv", range_in: Optional[str] = None,
                   range_out: str = "tv", lut_depth: Optional[int] = None, out_pix_fmt: Optional[str] = None,
-                  row0: int = 0, rows: Optional[int] = None):
-        """Fused YUV -> RGB -> lut3d -> RGB -> YUV on planar frames (Y, Cb, Cr)."""
+                  row0: int = 0, rows: Optional[int] = None, dither: str = "none"):
+        """Fused YUV -> RGB -> lut3d -> RGB -> YUV on planar frames (Y, Cb, Cr).
+        dither="error_diffusion" (the reference's `zscale_dither`) dithers the final quantisation; whole frames only."""
+        if dither not in _native.DITHER:
+            raise ValueError(f"unknown dither mode '{dither}'")
         fin = parse_pix_fmt(pix_fmt)
         fout = parse_pix_fmt(out_pix_fmt or pix_fmt)
         if fin.family != "yuv" or fout.family != "yuv":
@@ -275,6 +278,12 @@ class LutEngine:
             raise ValueError("src and dst disagree on the number of frames")
         rows = h - row0 if rows is None else rows
         self._bind_stream()
+        if dither != "none":
+            if row0 != 0 or rows != h:
+                raise ValueError("error-diffusion dither couples the rows of a frame: whole frames only")
+            _native.check(self._lib.lutr_apply_yuv_dither(
+                self._ctx, C.byref(p), _native.INTERP[interp], _native.DITHER[dither], w, h, nf, C.byref(s), C.byref(d)))
+            return dst
         _native.check(self._lib.lutr_apply_yuv(
             self._ctx, C.byref(p), _native.INTERP[interp], w, h, nf, C.byref(s), C.byref(d), row0, rows))
         return dst

@@ -74,6 +74,10 @@ def load() -> C.CDLL:
         lib.orc_yuv_constants.argtypes = [C.c_int] * 9 + [C.POINTER(YuvConsts)]
         lib.orc_apply_yuv.argtypes = [C.POINTER(OrcLut), C.c_int, C.POINTER(YuvConsts)] + [C.c_int] * 7 + \
                                      [P3, S3, P3, S3, C.c_int]
+        lib.orc_apply_yuv_dither.argtypes = lib.orc_apply_yuv.argtypes
+        lib.orc_dither_plane.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                         C.c_ssize_t]
+        lib.orc_dither_plane.restype = None
         _lib = lib
     return _lib
 
@@ -180,8 +184,11 @@ def yuv_constants(matrix_in="bt709", range_in="tv", matrix_out=None, range_out="
 
 
 def apply_yuv(table, scale, interp: str, consts: YuvConsts, din: int, dl: int, dout: int,
-              csx: int, csy: int, planes, nthreads: int = 1):
-    """planes: (Y, Cb, Cr) arrays; returns new (Y, Cb, Cr) with the output container dtype."""
+              csx: int, csy: int, planes, nthreads: int = 1, dither: str = "none"):
+    """planes: (Y, Cb, Cr) arrays; returns new (Y, Cb, Cr) with the output container dtype.
+    dither="error_diffusion": Floyd-Steinberg on the final quantisation (orc_apply_yuv_dither)."""
+    if dither not in ("none", "error_diffusion"):
+        raise ValueError(dither)
     lut, _keep = _lut_struct(table, scale)
     src = [np.ascontiguousarray(p) for p in planes]
     odt = np.uint8 if dout <= 8 else np.uint16
@@ -189,8 +196,18 @@ def apply_yuv(table, scale, interp: str, consts: YuvConsts, din: int, dl: int, d
     h, w = src[0].shape
     sp, ss = _plane_args(src)
     dp, ds = _plane_args(dst)
-    rc = load().orc_apply_yuv(C.byref(lut), INTERP[interp], C.byref(consts), din, dl, dout, csx, csy, w, h,
-                              sp, ss, dp, ds, nthreads)
+    fn = load().orc_apply_yuv if dither == "none" else load().orc_apply_yuv_dither
+    rc = fn(C.byref(lut), INTERP[interp], C.byref(consts), din, dl, dout, csx, csy, w, h, sp, ss, dp, ds, nthreads)
     if rc:
         raise OracleError(rc)
+    return dst
+
+
+def dither_plane(x, maxv: float, wide: bool):
+    """Floyd-Steinberg error diffusion of one float plane [H,W] to integer codes (orc_dither_plane)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    h, w = x.shape
+    dst = np.zeros((h, w), dtype=np.uint16 if wide else np.uint8)
+    load().orc_dither_plane(x.ctypes.data_as(C.POINTER(C.c_float)), w, h, C.c_float(maxv), int(bool(wide)),
+                            dst.ctypes.data_as(C.c_void_p), C.c_ssize_t(dst.strides[0]))
     return dst

@@ -804,6 +804,7 @@ typedef struct {
     const uint8_t *src[3]; ptrdiff_t ss[3];
     uint8_t *dst[3]; ptrdiff_t ds[3];
     lut_consts lk;
+    float *fdst[3]; int fw[3];      /* dither path: unquantised output planes (values before the +0.5 / floor) */
 } yuv_job;
 
 static inline float clip_floor(float v, float hi)
@@ -850,18 +851,24 @@ static void yuv_slice(void *arg, int y0, int y1)
                               j->lk.maxf, j->lk.maxi, (int)rf, (int)gf, (int)bf, &ro, &go, &bo);
                     rs += (float)ro; gs += (float)go; bs += (float)bo;
                     if (by + dy < j->h && bx + dx < j->w) {
-                        const float yo = clip_floor(
-                            fmaf(k->cyr, (float)ro, fmaf(k->cyg, (float)go, fmaf(k->cyb, (float)bo, k->yob))),
-                            k->max_o);
-                        st(j->dst[0] + y * j->ds[0], x, wo, (int)yo);
+                        const float yf = fmaf(k->cyr, (float)ro, fmaf(k->cyg, (float)go, fmaf(k->cyb, (float)bo, k->yob)));
+                        if (j->fdst[0])
+                            j->fdst[0][(size_t)y * j->fw[0] + x] = yf - 0.5f;
+                        else
+                            st(j->dst[0] + y * j->ds[0], x, wo, (int)clip_floor(yf, k->max_o));
                     }
                 }
             }
             {
-                const float cbo = clip_floor(fmaf(k->cbr, rs, fmaf(k->cbg, gs, fmaf(k->cbb, bs, k->cob))), k->max_o);
-                const float cro = clip_floor(fmaf(k->crr, rs, fmaf(k->crg, gs, fmaf(k->crb, bs, k->cob))), k->max_o);
-                st(j->dst[1] + cy * j->ds[1], cx, wo, (int)cbo);
-                st(j->dst[2] + cy * j->ds[2], cx, wo, (int)cro);
+                const float cbf = fmaf(k->cbr, rs, fmaf(k->cbg, gs, fmaf(k->cbb, bs, k->cob)));
+                const float crf = fmaf(k->crr, rs, fmaf(k->crg, gs, fmaf(k->crb, bs, k->cob)));
+                if (j->fdst[1]) {
+                    j->fdst[1][(size_t)cy * j->fw[1] + cx] = cbf - 0.5f;
+                    j->fdst[2][(size_t)cy * j->fw[2] + cx] = crf - 0.5f;
+                } else {
+                    st(j->dst[1] + cy * j->ds[1], cx, wo, (int)clip_floor(cbf, k->max_o));
+                    st(j->dst[2] + cy * j->ds[2], cx, wo, (int)clip_floor(crf, k->max_o));
+                }
             }
         }
     }
@@ -884,8 +891,80 @@ int orc_apply_yuv(const orc_lut *lut, int mode, const orc_yuv_consts *k,
     for (int c = 0; c < 3; c++) {
         j.src[c] = (const uint8_t *)src[c]; j.ss[c] = sstride[c];
         j.dst[c] = (uint8_t *)dst[c]; j.ds[c] = dstride[c];
+        j.fdst[c] = NULL; j.fw[c] = 0;
     }
     make_lut_consts(lut, dl, &j.lk);
     run_slices(yuv_slice, &j, h, 1 << csy, nthreads);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* error-diffusion dither of the final quantisation (SURVEY.md 8a a9,   */
+/* reference ffmpeg.py:305-307 `zscale=dither=error_diffusion`).        */
+/* The engine's own contract, modelled on zimg's dither_ed [recall]:    */
+/* Floyd-Steinberg, every row left to right, errors of the row above    */
+/* read with zero padding; float ops in exactly this order.             */
+/* ------------------------------------------------------------------ */
+void orc_dither_plane(const float *x, int w, int h, float maxv, int wide, void *dst, ptrdiff_t dstride)
+{
+    float *top = (float *)calloc((size_t)w + 2, sizeof(float));
+    float *cur = (float *)calloc((size_t)w + 2, sizeof(float));
+    if (!top || !cur) { free(top); free(cur); return; }
+    for (int y = 0; y < h; y++) {
+        float err_left = 0.0f;
+        uint8_t *drow = (uint8_t *)dst + y * dstride;
+        for (int j = 0; j < w; j++) {
+            /* error rows are padded by one on each side: index j+1 is column j */
+            float v = x[(size_t)y * w + j];
+            float err = 0.0f;
+            float q;
+            err += err_left * (7.0f / 16.0f);
+            err += top[j + 2] * (3.0f / 16.0f);
+            err += top[j + 1] * (5.0f / 16.0f);
+            err += top[j] * (1.0f / 16.0f);
+            v += err;
+            v = fminf(fmaxf(v, 0.0f), maxv);
+            q = rintf(v);                       /* round half to even, like lrintf in the default mode */
+            err_left = v - q;
+            cur[j + 1] = err_left;
+            st(drow, j, wide, (int)q);
+        }
+        { float *t = top; top = cur; cur = t; }
+    }
+    free(top);
+    free(cur);
+}
+
+int orc_apply_yuv_dither(const orc_lut *lut, int mode, const orc_yuv_consts *k,
+                         int din, int dl, int dout, int csx, int csy, int w, int h,
+                         const void *const src[3], const ptrdiff_t sstride[3],
+                         void *const dst[3], const ptrdiff_t dstride[3], int nthreads)
+{
+    yuv_job j;
+    if (!lut || !lut->rgb || !k || w < 0 || h < 0 || csx < 0 || csx > 1 || csy < 0 || csy > 1 ||
+        din < 8 || din > 16 || dl < 8 || dl > 16 || dout < 8 || dout > 16 ||
+        mode < ORC_NEAREST || mode > ORC_PRISM)
+        return ORC_EINVAL;
+    if (w == 0 || h == 0)
+        return 0;
+    const int cw = (w + (1 << csx) - 1) >> csx, chh = (h + (1 << csy) - 1) >> csy;
+    j.lut = lut; j.mode = mode; j.k = k;
+    j.din = din; j.dl = dl; j.dout = dout; j.csx = csx; j.csy = csy; j.w = w; j.h = h;
+    for (int c = 0; c < 3; c++) {
+        j.src[c] = (const uint8_t *)src[c]; j.ss[c] = sstride[c];
+        j.dst[c] = (uint8_t *)dst[c]; j.ds[c] = dstride[c];
+        j.fw[c] = c ? cw : w;
+        j.fdst[c] = (float *)malloc((size_t)j.fw[c] * (c ? chh : h) * sizeof(float));
+        if (!j.fdst[c]) {
+            for (int d = 0; d < c; d++) free(j.fdst[d]);
+            return ORC_ENOMEM;
+        }
+    }
+    make_lut_consts(lut, dl, &j.lk);
+    run_slices(yuv_slice, &j, h, 1 << csy, nthreads);
+    for (int c = 0; c < 3; c++) {
+        orc_dither_plane(j.fdst[c], j.fw[c], c ? chh : h, k->max_o, dout > 8, dst[c], dstride[c]);
+        free(j.fdst[c]);
+    }
     return 0;
 }

@@ -94,6 +94,15 @@ int orc_apply_yuv(const orc_lut *lut, int interp, const orc_yuv_consts *k,
                   const void *const src[3], const ptrdiff_t sstride[3],
                   void *const dst[3], const ptrdiff_t dstride[3], int nthreads);
 
+/* the same path with error-diffusion dither on the final quantisation (reference ffmpeg.py:305-307,
+ * `zscale=dither=error_diffusion`); whole frames only.  orc_dither_plane is the Floyd-Steinberg step
+ * alone: x = w*h unquantised values, dst = integer plane (uint8, or uint16 when wide). */
+int orc_apply_yuv_dither(const orc_lut *lut, int mode, const orc_yuv_consts *k,
+                         int din, int dl, int dout, int csx, int csy, int w, int h,
+                         const void *const src[3], const ptrdiff_t sstride[3],
+                         void *const dst[3], const ptrdiff_t dstride[3], int nthreads);
+void orc_dither_plane(const float *x, int w, int h, float maxv, int wide, void *dst, ptrdiff_t dstride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,6 +223,13 @@ def test_apply_lut_api_follows_the_reference_options(engine, orc, cube_dir):
     assert tags is None
     with pytest.raises(ValueError):
         apply_lut(_to_dev(src, engine), cube=None, interp="cubic", pix_fmt="yuv420p10le", engine=engine)
+    # zscale_dither=error_diffusion with a 10-bit source going to 8-bit yuv420p (force_8bit policy, ffmpeg.py:288-291)
+    out, _ = apply_lut(_to_dev(src, engine), cube=None, pix_fmt="yuv420p10le", colorspace="bt2020nc", color_range="tv",
+                       out_pix_fmt="yuv420p", zscale_dither="error_diffusion", engine=engine)
+    k = orc.yuv_constants("bt2020nc", "tv", "bt2020nc", "tv", 10, 10, 8, 4)
+    _assert_equal([t.cpu().numpy() for t in out],
+                  orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 8, 1, 1, src, dither="error_diffusion"),
+                  "apply_lut dithered")
 
 
 def test_tile_window_statistics(engine, cube_dir):
@@ -532,3 +539,48 @@ def test_bench_two_ranks_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["config"]["parallelism"] == "row-block x2" and "tile" in d["config"]["kernel"]
+
+
+@pytest.mark.parametrize("fmt,out_fmt,w,h,nframes", [
+    ("yuv420p10le", "yuv420p10le", 256, 200, 2),     # 4 bands of 64 rows: bands pipelined over several waves
+    ("yuv420p10le", "yuv420p", 320, 136, 1),         # 10-bit LUT path, 8-bit dithered output (the reference's use)
+    ("yuv420p", "yuv420p", 128, 64, 3),
+    ("yuv444p10le", "yuv444p10le", 64, 130, 1),
+    ("yuv422p10le", "yuv422p10le", 74, 70, 1),
+    ("yuv420p10le", "yuv420p10le", 37, 19, 2),       # odd sizes: edge replication into the last chroma block
+    ("yuv420p", "yuv420p", 2, 2, 1),
+])
+def test_error_diffusion_dither_parity(engine, orc, cube_dir, fmt, out_fmt, w, h, nframes):
+    """`zscale_dither=error_diffusion`.  Floyd-Steinberg is sequential, so any slip in
+    the skewed-wave pipeline shows up as a different bit pattern; the bar is exact equality."""
+    from lut_renderer_amd.engine import parse_pix_fmt
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    fin, fout = parse_pix_fmt(fmt), parse_pix_fmt(out_fmt)
+    k = orc.yuv_constants(din=fin.depth, dl=fin.depth, dout=fout.depth, chroma_n=1 << (fin.csx + fin.csy))
+    batch = [frames.natural_yuv(w, h, fin.depth, fin.csx, fin.csy, k=i) for i in range(nframes)]
+    for mode in ("tetrahedral", "trilinear"):
+        want = [orc.apply_yuv(lut.table, lut.scale, mode, k, fin.depth, fin.depth, fout.depth, fin.csx, fin.csy, f,
+                              dither="error_diffusion") for f in batch]
+        src = [torch.from_numpy(np.stack([f[i] for f in batch]).view(np.int16 if fin.depth > 8 else np.uint8))
+               .to(engine.device) for i in range(3)]
+        got = engine.apply_yuv(src, pix_fmt=fmt, out_pix_fmt=out_fmt, interp=mode, dither="error_diffusion")
+        assert "dither" in engine.last_kernel
+        for i in range(3):
+            g = got[i].cpu().numpy()
+            g = g.view(np.uint16) if fout.depth > 8 else g
+            for fr in range(nframes):
+                _assert_equal([g[fr]], [want[fr][i]], f"dither {fmt}->{out_fmt} {mode} plane {i} frame {fr}")
+    with pytest.raises(ValueError):
+        engine.apply_yuv(src, pix_fmt=fmt, out_pix_fmt=out_fmt, dither="error_diffusion", row0=0, rows=h // 2 & ~1)
+    with pytest.raises(ValueError):
+        engine.apply_yuv(src, pix_fmt=fmt, out_pix_fmt=out_fmt, dither="ordered")
+
+
+def test_error_diffusion_dither_1080p_frame(engine, orc, cube_dir):
+    """A full 1080p frame: 17 bands, wide error rows (the LDS budget picks the number of waves per plane)."""
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    src = frames.natural_yuv(1920, 1080, 10, 1, 1, k=1)
+    k = orc.yuv_constants(din=10, dl=10, dout=8)
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 8, 1, 1, src, nthreads=8, dither="error_diffusion")
+    got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le", out_pix_fmt="yuv420p", dither="error_diffusion")
+    _assert_equal([t.cpu().numpy() for t in got], want, "dither 1080p")
