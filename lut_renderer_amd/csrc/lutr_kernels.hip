@@ -200,6 +200,24 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     if (variant == VAR_GENERIC) vec_ok = false;
     if (vec_ok && (variant == VAR_AUTO || variant == VAR_VEC_LDS))
         return launch_rgb_tile(st, L, P, G, depth, mode, stats, queue);
+    // A ragged width on aligned (padded) rows: the fast kernel takes the columns up to the last multiple of
+    // its unit, the scalar kernel the few that remain (each pixel is independent, so any split is exact).
+    const int wv = G.w / pxt * pxt;
+    if (variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w &&
+        (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
+        (long long)wv * G.rows * G.nframes / pxt < 0x7fffffffll &&
+        planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, 16, G.nframes > 1) &&
+        planes_aligned(P, 2, 16, G.nframes > 1)) {
+        FrameGeom Gv = G, Ge = G;
+        Gv.w = wv;
+        Ge.w = G.w - wv;
+        PlaneSet Pe = P;
+        for (int c = 0; c < 3; c++) { Pe.s[c] += (long long)wv * (wide ? 2 : 1); Pe.d[c] += (long long)wv * (wide ? 2 : 1); }
+        const char *name = launch_rgb_tile(st, L, P, Gv, depth, mode, stats, queue);
+        hipLaunchKernelGGL(k_rgb_generic, dim3(grid_for((long long)Ge.w * G.rows * G.nframes, 256 * 64)), dim3(256), 0, st,
+                           L, Pe, Ge, wide, mode);
+        return name;
+    }
     if (!vec_ok) {
         if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
         // grid-stride; enough blocks to fill 256 CUs x 8
@@ -235,6 +253,28 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     if (variant == VAR_GENERIC) vec_ok = false;
     if (vec_ok && (variant == VAR_AUTO || variant == VAR_VEC_LDS))
         return launch_yuv_tile(st, L, K, P, G, win, csx, csy, mode, stats, queue);
+    // ragged width on aligned (padded) rows: fast kernel up to the last whole unit, scalar kernel for the rest
+    // (the split falls on a chroma-block boundary: the unit is 8 or 16 luma samples wide)
+    const int wv = G.w / pxt * pxt;
+    if (variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w &&
+        (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
+        win == wout && G.row0 % bh == 0 && G.rows % bh == 0 && !(csx == 0 && csy == 1) &&
+        (long long)(wv / pxt) * (G.rows >> csy) * G.nframes < 0x7fffffffll &&
+        planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, cbytes, G.nframes > 1) &&
+        planes_aligned(P, 2, cbytes, G.nframes > 1)) {
+        FrameGeom Gv = G, Ge = G;
+        Gv.w = wv;
+        Ge.w = G.w - wv;
+        PlaneSet Pe = P;
+        const long long bs = win ? 2 : 1;
+        Pe.s[0] += wv * bs; Pe.d[0] += wv * bs;
+        for (int c = 1; c < 3; c++) { Pe.s[c] += (wv >> csx) * bs; Pe.d[c] += (wv >> csx) * bs; }
+        const char *name = launch_yuv_tile(st, L, K, P, Gv, win, csx, csy, mode, stats, queue);
+        const long long eb = (long long)((Ge.w + (1 << csx) - 1) >> csx) * ((G.rows + bh - 1) >> csy) * G.nframes;
+        hipLaunchKernelGGL(k_yuv_generic, dim3(grid_for(eb, 256 * 64)), dim3(256), 0, st, L, K, Pe, Ge, win, wout,
+                           csx, csy, mode);
+        return name;
+    }
     if (!vec_ok) {
         if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
         const long long blocks = (long long)((G.w + (1 << csx) - 1) >> csx) * ((G.rows + bh - 1) >> csy) * G.nframes;

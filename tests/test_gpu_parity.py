@@ -584,3 +584,44 @@ def test_error_diffusion_dither_1080p_frame(engine, orc, cube_dir):
     want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 8, 1, 1, src, nthreads=8, dither="error_diffusion")
     got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le", out_pix_fmt="yuv420p", dither="error_diffusion")
     _assert_equal([t.cpu().numpy() for t in got], want, "dither 1080p")
+
+
+@pytest.mark.parametrize("fmt,w", [("yuv420p10le", 166), ("yuv420p10le", 165), ("yuv420p", 89), ("yuv422p10le", 70),
+                                   ("yuv444p10le", 43), ("gbrp10le", 77), ("gbrp", 50)])
+def test_ragged_width_on_padded_rows_splits_between_fast_and_scalar_kernels(engine, orc, cube_dir, fmt, w):
+    """Decoder-style frames: a width that is not a multiple of the fast kernel's unit (1366, DCI 1998, ...) in
+    rows padded to an aligned stride.  The tile kernel takes the whole units, the scalar kernel the rest."""
+    from lut_renderer_amd.engine import parse_pix_fmt
+    lut = _load(engine, cube_dir, "log709_33.cube")
+    pf = parse_pix_fmt(fmt)
+    h, nf = 36, 2
+    esz = 2 if pf.depth > 8 else 1
+    tdt = torch.int16 if esz == 2 else torch.uint8
+    if pf.family == "gbr":
+        frames_np = [frames.natural_rgb(w, h, pf.depth, k=i) for i in range(nf)]
+    else:
+        frames_np = [frames.natural_yuv(w, h, pf.depth, pf.csx, pf.csy, k=i) for i in range(nf)]
+    src, dst = [], []
+    for i in range(3):
+        ph, pw = pf.plane_shape(i, w, h)
+        stride = ((pw * esz + 8 + 63) // 64) * 64 // esz            # rows padded to a 64-byte multiple, like a decoder's
+        buf = torch.zeros((nf, ph, stride), dtype=tdt, device=engine.device)
+        arr = np.stack([f[i] for f in frames_np])
+        buf[:, :, :pw] = torch.from_numpy(arr.view(np.int16) if esz == 2 else arr).to(engine.device)
+        src.append(buf[:, :, :pw])
+        dst.append(torch.full_like(buf, 0x55)[:, :, :pw])
+    for mode in ("tetrahedral", "trilinear"):
+        if pf.family == "gbr":
+            got = engine.apply_rgb(src, dst, depth=pf.depth, interp=mode)
+            want = [orc.apply_rgb(lut.table, lut.scale, pf.depth, mode, f) for f in frames_np]
+        else:
+            got = engine.apply_yuv(src, dst, pix_fmt=fmt, interp=mode)
+            k = orc.yuv_constants(din=pf.depth, chroma_n=1 << (pf.csx + pf.csy))
+            want = [orc.apply_yuv(lut.table, lut.scale, mode, k, pf.depth, pf.depth, pf.depth, pf.csx, pf.csy, f)
+                    for f in frames_np]
+        assert "tile" in engine.last_kernel, engine.last_kernel
+        for i in range(3):
+            g = got[i].cpu().numpy()
+            g = g.view(np.uint16) if esz == 2 else g
+            for fr in range(nf):
+                _assert_equal([g[fr]], [want[fr][i]], f"ragged {fmt} w={w} {mode} plane {i} frame {fr}")
