@@ -20,8 +20,8 @@
 //     bounds reduced across the wave, the window re-staged from L2 (or, if the tile's
 //     colours do not fit, the tile routed to the global-gather body) and the tile redone.
 //     Waves walk DOWN a column strip, so consecutive tiles mostly hit.
-//   * No workgroup barrier anywhere: waves are independent; a wave's only shared state
-//     is its own LDS slice.
+//   * No workgroup barrier in the tile loop (one at kernel start, after the coordinate table is
+//     filled): waves are independent; a wave's only shared state is its own LDS slice.
 //
 // Arithmetic is the strict restatement (see lutr_kernels.hip): -ffp-contract=off, FFmpeg's
 // scalar C order, bit-identical to the oracle.
@@ -68,11 +68,15 @@ __device__ __forceinline__ float in_vgpr(float s)
 struct Win {
     // byte address of the tap at cell (pr,pg,pb): (int) fma(pr, fr, fma(pg, fg, fma(pb, fb, fc)))
     float fr, fg, fb, fc;
-    int   o_r, o_g, o_b;                          // byte steps of +1 along r, g, b
+    int   o_r, o_g;                               // byte steps of +1 along r and g (blue is always kOB)
     unsigned a_max;                               // LDS only: highest base address whose 8 corners stay inside
                                                   // the workgroup's allocation (optimistic reads never leave it)
     float r_lo, r_hi, g_lo, g_hi, b_lo, b_hi;     // cells (pr, pg-pr, pb-pr) whose 8 corners are staged
 };
+
+// Blue is the fastest axis of the global lattice and of every LDS window: its step is one 16-byte node.
+// A compile-time constant lets the +1-blue taps use the immediate offset field of ds_read / global_load.
+constexpr int kOB = 16;
 
 struct Bnd { float rmin, rmax, gmin, gmax, bmin, bmax; };
 
@@ -208,7 +212,7 @@ __device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const
         const float x = fmaxf(fmaxf(dr, dg), db), y = tmed3(dr, dg, db), z = fminf(fminf(dr, dg), db);
         const bool rg = dr > dg, gb = dg > db, rb = dr > db;
         // by-value copies: a ?: over struct members is an lvalue select, which pins W in scratch
-        const int o_r = W.o_r, o_g = W.o_g, o_b = W.o_b;
+        const int o_r = W.o_r, o_g = W.o_g, o_b = kOB;
         const int o111 = o_r + o_g + o_b;
         const int z_r = o111 - o_r, z_g = o111 - o_g, z_b = o111 - o_b;
         // first step along the axis of the largest fraction, last step along the smallest
@@ -247,10 +251,11 @@ __device__ __forceinline__ Rgb3 px_blend(const LutConsts &L, const Win &W, const
         v.r = t.x; v.g = t.y; v.b = t.z;
     } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
         const float dr = c.w0, dg = c.w1, db = c.w2;
-        const f4 c000 = tap<LDS>(L.lat, a), c001 = tap<LDS>(L.lat, a + W.o_b);
-        const f4 c010 = tap<LDS>(L.lat, a + W.o_g), c011 = tap<LDS>(L.lat, a + W.o_g + W.o_b);
-        const f4 c100 = tap<LDS>(L.lat, a + W.o_r), c101 = tap<LDS>(L.lat, a + W.o_r + W.o_b);
-        const f4 c110 = tap<LDS>(L.lat, a + W.o_r + W.o_g), c111 = tap<LDS>(L.lat, a + W.o_r + W.o_g + W.o_b);
+        const int ag = a + W.o_g, ar = a + W.o_r, arg = ar + W.o_g;       // 3 address adds; +blue is an immediate
+        const f4 c000 = tap<LDS>(L.lat, a), c001 = tap<LDS>(L.lat, a + kOB);
+        const f4 c010 = tap<LDS>(L.lat, ag), c011 = tap<LDS>(L.lat, ag + kOB);
+        const f4 c100 = tap<LDS>(L.lat, ar), c101 = tap<LDS>(L.lat, ar + kOB);
+        const f4 c110 = tap<LDS>(L.lat, arg), c111 = tap<LDS>(L.lat, arg + kOB);
 #define TRI(ch, out) \
         { \
             const float c00 = tlerp(c000.ch, c100.ch, dr), c10 = tlerp(c010.ch, c110.ch, dr); \
@@ -261,7 +266,7 @@ __device__ __forceinline__ Rgb3 px_blend(const LutConsts &L, const Win &W, const
         TRI(x, v.r) TRI(y, v.g) TRI(z, v.b)
 #undef TRI
     } else {
-        const int o111 = W.o_r + W.o_g + W.o_b;
+        const int o111 = W.o_r + W.o_g + kOB;
         const f4 c0 = tap<LDS>(L.lat, a), c1 = tap<LDS>(L.lat, a + c.oa);
         const f4 c2 = tap<LDS>(L.lat, a + c.oz), c3 = tap<LDS>(L.lat, a + o111);
         v.r = c.w0 * c0.x + c.w1 * c1.x + c.w2 * c2.x + c.w3 * c3.x;
@@ -296,7 +301,7 @@ __device__ __forceinline__ void win_global(Win &W, const LutConsts &L)
 {
     const int n1 = L.n1;
     W.fr = W.fg = W.fb = W.fc = 0.0f;             // unused: the global body addresses with integers
-    W.o_r = 16 * n1 * n1; W.o_g = 16 * n1; W.o_b = 16;
+    W.o_r = 16 * n1 * n1; W.o_g = 16 * n1;
     W.a_max = 0;
     W.r_lo = W.g_lo = W.b_lo = 1.0f;
     W.r_hi = W.g_hi = W.b_hi = 0.0f;
@@ -307,7 +312,7 @@ __device__ __forceinline__ void win_global(Win &W, const LutConsts &L)
 __device__ __forceinline__ void win_empty(Win &W, int slice_off)
 {
     W.fr = W.fg = W.fb = 0.0f; W.fc = (float)(lds_base() + slice_off);
-    W.o_r = W.o_g = W.o_b = 0;
+    W.o_r = W.o_g = 0;
     W.a_max = (unsigned)(lds_base() + slice_off);
     W.r_lo = W.g_lo = W.b_lo = 1.0f;
     W.r_hi = W.g_hi = W.b_hi = 0.0f;
@@ -362,10 +367,10 @@ __device__ __forceinline__ bool win_restage(Win &W, const LutConsts &L, const Bn
         *(float4 *)(lutr_smem + slice_off + 16 * (ir * sr + ig * nb + ib)) = v;
     }
     // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pr-b0)
-    W.o_r = 16 * (sr - nb - 1); W.o_g = 16 * nb; W.o_b = 16;
+    W.o_r = 16 * (sr - nb - 1); W.o_g = 16 * nb;
     W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = 16.0f;
     W.fc = (float)(lds_base() + slice_off - 16 * (r0 * sr + g0 * nb + b0));
-    W.a_max = (unsigned)(lds_base() + lds_bytes - (W.o_r + W.o_g + W.o_b) - 16);
+    W.a_max = (unsigned)(lds_base() + lds_bytes - (W.o_r + W.o_g + kOB) - 16);
     W.r_lo = (float)r0;       W.r_hi = (float)(r0 + nr - 2);
     W.g_lo = (float)(g0 + 1); W.g_hi = (float)(g0 + ng - 2);
     W.b_lo = (float)(b0 + 1); W.b_hi = (float)(b0 + nb - 2);
