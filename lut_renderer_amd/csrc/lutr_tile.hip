@@ -27,9 +27,16 @@
 // scalar C order, bit-identical to the oracle.
 #include <cstdio>
 #include <cstdlib>
+#include <set>
 
 #include "lutr_internal.h"
 
+
+// Waves per workgroup.  The waves of a block share one coordinate table, so bigger blocks leave more of the
+// CU's 160 KB to the windows (4 waves -> 512 nodes per wave at 10 bit, 8 -> 576, 16 -> 608; 8 measured best).
+#ifndef LUTR_WPB
+#define LUTR_WPB 8
+#endif
 
 namespace lutr {
 
@@ -181,7 +188,7 @@ __device__ __forceinline__ Crd crd_table(unsigned code)
 template <int INTERP>
 __device__ __forceinline__ void coord_table_fill(const LutConsts &L, int entries)
 {
-    for (int q = threadIdx.x; q < entries; q += 256) {
+    for (int q = threadIdx.x; q < entries; q += 64 * LUTR_WPB) {
         const Crd c = crd_compute<INTERP>(L, (float)q, L.sc[0]);
         *(float2 *)(lutr_smem + q * 8) = make_float2(c.p, c.d);
     }
@@ -636,7 +643,7 @@ __device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &f
 }
 
 template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
-__global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
+__global__ __launch_bounds__(64 * LUTR_WPB, LUTR_TILE_WAVES_PER_EU)
 void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG)
 {
     LutConsts L = L_;
@@ -650,7 +657,7 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
     using T = YuvTile<WIDE, CSX, CSY>;
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
-    const int wave = blockIdx.x * 4 + wib;
+    const int wave = blockIdx.x * LUTR_WPB + wib;
     const int slice_off = TG.tab_bytes + wib * TG.win_nodes * 16;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
@@ -658,7 +665,7 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
 
-    const int lds_bytes = TG.tab_bytes + 4 * TG.win_nodes * 16;
+    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * 16;
     Win W, WG;
     win_empty(W, slice_off);
     win_global(WG, L);
@@ -833,7 +840,7 @@ __device__ __forceinline__ void rgb_tile_bounds(const LutConsts &L, RgbTile<WIDE
 }
 
 template <int WIDE, int INTERP, int TAB>
-__global__ __launch_bounds__(256, LUTR_TILE_WAVES_PER_EU)
+__global__ __launch_bounds__(64 * LUTR_WPB, LUTR_TILE_WAVES_PER_EU)
 void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
 {
     LutConsts L = L_;
@@ -848,7 +855,7 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
 
-    const int lds_bytes = TG.tab_bytes + 4 * TG.win_nodes * 16;
+    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * 16;
     Win W, WG;
     win_empty(W, slice_off);
     win_global(WG, L);
@@ -970,7 +977,7 @@ static int tile_blocks(const TileGeom &tg, int waves_per_cu)
 {
     const int max_waves = device_cus() * waves_per_cu;
     const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
-    return (waves + 3) / 4;
+    return (waves + LUTR_WPB - 1) / LUTR_WPB;
 }
 
 static int g_win_nodes = 640;       // 10 KB per wave, 40 KB per 256-thread block, 4 blocks per CU = all 160 KB
@@ -998,10 +1005,22 @@ static int plan_table(TileGeom *tg, const LutConsts &L)
     const int entries = (int)L.maxf + 1;
     const bool ok = L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2] && entries <= 1024 && !getenv("LUTR_NO_TAB");
     tg->tab_bytes = ok ? entries * 8 : 0;
-    const int cap = (40960 - tg->tab_bytes) / 64;                // nodes per wave with 4 blocks of 4 waves per CU
+    const int blocks_per_cu = g_waves_per_cu / LUTR_WPB > 0 ? g_waves_per_cu / LUTR_WPB : 1;
+    const int cap = (163840 / blocks_per_cu - tg->tab_bytes) / (16 * LUTR_WPB);   // nodes per wave: the CU's 160 KB over its resident blocks
     if (tg->tab_bytes && tg->win_nodes > cap) tg->win_nodes = cap;
     return tg->tab_bytes;
 }
+
+// Blocks of more than 4 waves need more than the default 64 KB of dynamic LDS: allow it once per kernel.
+static void allow_lds(const void *kernel, size_t bytes)
+{
+    static std::set<const void *> done;
+    if (bytes <= 65536 || done.count(kernel)) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.insert(kernel);
+}
+#define LUTR_LAUNCH_TILE(kernel, ...) \
+    do { allow_lds((const void *)(kernel), lds); hipLaunchKernelGGL((kernel), grid, block, lds, st, __VA_ARGS__); } while (0)
 
 const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G, int depth, int mode,
                             unsigned *stats, unsigned *queue)
@@ -1011,14 +1030,14 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     read_env_tuning();
     plan_tiles(&tg, G.w / pxt, G.rows, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
     if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
-    const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(256);
+    const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
     const bool tab = plan_table(&tg, L) != 0;
-    const size_t lds = (size_t)tg.tab_bytes + (size_t)4 * tg.win_nodes * 16;
+    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * 16;
 #define RGB_CASE(W, I) \
     if (wide == W && mode == I) { \
-        if (tab && L.unit) hipLaunchKernelGGL((k_rgb_tile<W, I, 2>), grid, block, lds, st, L, P, G, tg); \
-        else if (tab) hipLaunchKernelGGL((k_rgb_tile<W, I, 1>), grid, block, lds, st, L, P, G, tg); \
-        else hipLaunchKernelGGL((k_rgb_tile<W, I, 0>), grid, block, lds, st, L, P, G, tg); \
+        if (tab && L.unit) LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 2>), L, P, G, tg); \
+        else if (tab) LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 1>), L, P, G, tg); \
+        else LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 0>), L, P, G, tg); \
         return tab ? (L.unit ? "k_rgb_tile<" #W "," #I ",tab,unit>" : "k_rgb_tile<" #W "," #I ",tab>") : "k_rgb_tile<" #W "," #I ">"; \
     }
     RGB_CASE(0, 0) RGB_CASE(0, 1) RGB_CASE(0, 2)
@@ -1049,25 +1068,25 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     read_env_tuning();
     plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
     if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
-    const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(256);
+    const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
     const bool tab = plan_table(&tg, L) != 0;
-    const size_t lds = (size_t)tg.tab_bytes + (size_t)4 * tg.win_nodes * 16;
+    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * 16;
     const bool pre = K.pre != 0.0f;
     // ",unit" kernels drop both output clips: lattice in [0,1] (quantisation) and YUV maxima below max_o + 1
     const bool unit = L.unit && out_clip_dead(K, 1 << (csx + csy));
     if (getenv("LUTR_DEBUG")) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false, 1>, 256, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false, 1>, 64 * LUTR_WPB, lds);
         fprintf(stderr, "[lutr] tiles %d nsx %d nry %d chunk %d nrc %d chunks %d blocks %u lds/block %zu occupancy(blocks/CU) %d cus %d\n",
                 tg.tiles, tg.nsx, tg.nry, tg.ch, tg.nrc, tg.nchunks, grid.x, lds, nb, device_cus());
     }
 #define YUV_CASE(W, X, Y, I) \
     if (win == W && csx == X && csy == Y && mode == I) { \
-        if (pre && tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, 1>), grid, block, lds, st, L, K, P, G, tg); \
-        else if (pre) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, true, 0>), grid, block, lds, st, L, K, P, G, tg); \
-        else if (tab && unit) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 2>), grid, block, lds, st, L, K, P, G, tg); \
-        else if (tab) hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 1>), grid, block, lds, st, L, K, P, G, tg); \
-        else hipLaunchKernelGGL((k_yuv_tile<W, X, Y, I, false, 0>), grid, block, lds, st, L, K, P, G, tg); \
+        if (pre && tab) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, true, 1>), L, K, P, G, tg); \
+        else if (pre) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, true, 0>), L, K, P, G, tg); \
+        else if (tab && unit) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 2>), L, K, P, G, tg); \
+        else if (tab) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 1>), L, K, P, G, tg); \
+        else LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 0>), L, K, P, G, tg); \
         return pre ? (tab ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre,tab>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre>") \
                    : (tab ? (unit ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab,unit>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab>") \
                           : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"); \
