@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--no-stats", action="store_true", help="skip the extra LDS-window statistics pass (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--extra", action="store_true", help="also time the other distribution / mode (stderr only)")
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="untimed kernel launches before the W warm-up steps until this much time has passed: the GPU "
+                         "needs ~20 ms of load to leave its idle clock (DESIGN.md 5), whatever W the caller picks")
     ap.add_argument("--dither", default="none", choices=["none", "error_diffusion"],
                     help="also dither the final quantisation (reference option zscale_dither; YUV formats, informational)")
     ap.add_argument("--pipeline", default="hbm", choices=["hbm", "host"],
@@ -138,7 +141,14 @@ def build_batch(eng, pf, w, h, r0, r1, nframes, dist_name, unique):
     return out
 
 
+PREWARM_MS = 0.0
+
+
 def time_steps(eng, pf, src, dst, fmt, interp, steps, warmup, world):
+    t_end = time.perf_counter() + PREWARM_MS / 1e3
+    while time.perf_counter() < t_end:                 # clock ramp; not part of W, not timed
+        apply(eng, pf, src, dst, fmt, interp)
+        torch.cuda.synchronize()
     for _ in range(warmup):
         apply(eng, pf, src, dst, fmt, interp)
     torch.cuda.synchronize()
@@ -201,8 +211,9 @@ def load_traffic(tag):
 
 def main():
     args = parse_args()
-    global DITHER
+    global DITHER, PREWARM_MS
     DITHER = args.dither
+    PREWARM_MS = args.prewarm_ms
     rank, local, world = dist_setup(args.gpus)
     from lut_renderer_amd import cube
     from lut_renderer_amd.engine import LutEngine, parse_pix_fmt
