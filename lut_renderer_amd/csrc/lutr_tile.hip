@@ -84,6 +84,15 @@ struct Win {
 // Blue is the fastest axis of the global lattice and of every LDS window: its step is one 16-byte node.
 // A compile-time constant lets the +1-blue taps use the immediate offset field of ds_read / global_load.
 constexpr int kOB = 16;
+// Bytes per node in an LDS window: 16 (the global float4 node, one ds_read_b128 per tap) or 12 ({r,g,b} only:
+// a third more nodes per wave, a tap = ds_read2_b32 + ds_read_b32).  Measured on the headline workload: 12-byte
+// nodes cut the gather tiles by a third (20,416 -> 13,728 of 518,400) and need 6 fewer VGPRs, but the extra LDS
+// instructions and cycles cost as much as that saves (487 vs 491 Gpx/s), so 16 stays.
+#ifndef LUTR_LDS_NODE
+#define LUTR_LDS_NODE 16
+#endif
+constexpr int kLN = LUTR_LDS_NODE;
+template <bool LDS> constexpr int node_b() { return LDS ? kLN : kOB; }
 
 struct Bnd { float rmin, rmax, gmin, gmax, bmin, bmax; };
 
@@ -143,8 +152,17 @@ __device__ __forceinline__ int lds_base()
 template <bool LDS>
 __device__ __forceinline__ f4 tap(const float4 *__restrict__ lat, int a)
 {
-    if constexpr (LDS) return *(lds_f4 *)(uintptr_t)(unsigned)a;
-    else return *(const f4 *)((const char *)lat + a);
+    if constexpr (LDS && kLN == 16) {
+        return *(lds_f4 *)(uintptr_t)(unsigned)a;
+    } else if constexpr (LDS) {
+        typedef const __attribute__((address_space(3))) float lds_f;
+        lds_f *p = (lds_f *)(uintptr_t)(unsigned)a;
+        f4 v;
+        v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = 0.0f;
+        return v;
+    } else {
+        return *(const f4 *)((const char *)lat + a);
+    }
 }
 
 struct Rgb3 { float r, g, b; };
@@ -219,7 +237,7 @@ __device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const
         const float x = fmaxf(fmaxf(dr, dg), db), y = tmed3(dr, dg, db), z = fminf(fminf(dr, dg), db);
         const bool rg = dr > dg, gb = dg > db, rb = dr > db;
         // by-value copies: a ?: over struct members is an lvalue select, which pins W in scratch
-        const int o_r = W.o_r, o_g = W.o_g, o_b = kOB;
+        const int o_r = W.o_r, o_g = W.o_g, o_b = node_b<LDS>();
         const int o111 = o_r + o_g + o_b;
         const int z_r = o111 - o_r, z_g = o111 - o_g, z_b = o111 - o_b;
         // first step along the axis of the largest fraction, last step along the smallest
@@ -259,10 +277,11 @@ __device__ __forceinline__ Rgb3 px_blend(const LutConsts &L, const Win &W, const
     } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
         const float dr = c.w0, dg = c.w1, db = c.w2;
         const int ag = a + W.o_g, ar = a + W.o_r, arg = ar + W.o_g;       // 3 address adds; +blue is an immediate
-        const f4 c000 = tap<LDS>(L.lat, a), c001 = tap<LDS>(L.lat, a + kOB);
-        const f4 c010 = tap<LDS>(L.lat, ag), c011 = tap<LDS>(L.lat, ag + kOB);
-        const f4 c100 = tap<LDS>(L.lat, ar), c101 = tap<LDS>(L.lat, ar + kOB);
-        const f4 c110 = tap<LDS>(L.lat, arg), c111 = tap<LDS>(L.lat, arg + kOB);
+        constexpr int ob = node_b<LDS>();
+        const f4 c000 = tap<LDS>(L.lat, a), c001 = tap<LDS>(L.lat, a + ob);
+        const f4 c010 = tap<LDS>(L.lat, ag), c011 = tap<LDS>(L.lat, ag + ob);
+        const f4 c100 = tap<LDS>(L.lat, ar), c101 = tap<LDS>(L.lat, ar + ob);
+        const f4 c110 = tap<LDS>(L.lat, arg), c111 = tap<LDS>(L.lat, arg + ob);
 #define TRI(ch, out) \
         { \
             const float c00 = tlerp(c000.ch, c100.ch, dr), c10 = tlerp(c010.ch, c110.ch, dr); \
@@ -273,7 +292,7 @@ __device__ __forceinline__ Rgb3 px_blend(const LutConsts &L, const Win &W, const
         TRI(x, v.r) TRI(y, v.g) TRI(z, v.b)
 #undef TRI
     } else {
-        const int o111 = W.o_r + W.o_g + kOB;
+        const int o111 = W.o_r + W.o_g + node_b<LDS>();
         const f4 c0 = tap<LDS>(L.lat, a), c1 = tap<LDS>(L.lat, a + c.oa);
         const f4 c2 = tap<LDS>(L.lat, a + c.oz), c3 = tap<LDS>(L.lat, a + o111);
         v.r = c.w0 * c0.x + c.w1 * c1.x + c.w2 * c2.x + c.w3 * c3.x;
@@ -371,13 +390,18 @@ __device__ __forceinline__ bool win_restage(Win &W, const LutConsts &L, const Bn
         // nodes outside the cube are never referenced by a valid pixel: clamp to stay in bounds
         r = min(max(r, 0), nmax); g = min(max(g, 0), nmax); b = min(max(b, 0), nmax);
         const float4 v = L.lat[(r * n1 + g) * n1 + b];
-        *(float4 *)(lutr_smem + slice_off + 16 * (ir * sr + ig * nb + ib)) = v;
+        if constexpr (kLN == 16) {
+            *(float4 *)(lutr_smem + slice_off + 16 * (ir * sr + ig * nb + ib)) = v;
+        } else {
+            float *q = (float *)(lutr_smem + slice_off + kLN * (ir * sr + ig * nb + ib));
+            q[0] = v.x; q[1] = v.y; q[2] = v.z;
+        }
     }
     // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pr-b0)
-    W.o_r = 16 * (sr - nb - 1); W.o_g = 16 * nb;
-    W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = 16.0f;
-    W.fc = (float)(lds_base() + slice_off - 16 * (r0 * sr + g0 * nb + b0));
-    W.a_max = (unsigned)(lds_base() + lds_bytes - (W.o_r + W.o_g + kOB) - 16);
+    W.o_r = kLN * (sr - nb - 1); W.o_g = kLN * nb;
+    W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)kLN;
+    W.fc = (float)(lds_base() + slice_off - kLN * (r0 * sr + g0 * nb + b0));
+    W.a_max = (unsigned)(lds_base() + lds_bytes - (W.o_r + W.o_g + kLN) - kLN);
     W.r_lo = (float)r0;       W.r_hi = (float)(r0 + nr - 2);
     W.g_lo = (float)(g0 + 1); W.g_hi = (float)(g0 + ng - 2);
     W.b_lo = (float)(b0 + 1); W.b_hi = (float)(b0 + nb - 2);
@@ -658,14 +682,14 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int wave = blockIdx.x * LUTR_WPB + wib;
-    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * 16;
+    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * kLN;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
 
-    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * 16;
+    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * kLN;
     Win W, WG;
     win_empty(W, slice_off);
     win_global(WG, L);
@@ -849,13 +873,13 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
     using T = RgbTile<WIDE>;
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
-    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * 16;
+    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * kLN;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
 
-    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * 16;
+    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * kLN;
     Win W, WG;
     win_empty(W, slice_off);
     win_global(WG, L);
@@ -980,7 +1004,7 @@ static int tile_blocks(const TileGeom &tg, int waves_per_cu)
     return (waves + LUTR_WPB - 1) / LUTR_WPB;
 }
 
-static int g_win_nodes = 640;       // 10 KB per wave, 40 KB per 256-thread block, 4 blocks per CU = all 160 KB
+static int g_win_nodes = 1024;       // 10 KB per wave, 40 KB per 256-thread block, 4 blocks per CU = all 160 KB
 static int g_waves_per_cu = 16;
 static bool g_env_read = false;
 
@@ -1006,8 +1030,8 @@ static int plan_table(TileGeom *tg, const LutConsts &L)
     const bool ok = L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2] && entries <= 1024 && !getenv("LUTR_NO_TAB");
     tg->tab_bytes = ok ? entries * 8 : 0;
     const int blocks_per_cu = g_waves_per_cu / LUTR_WPB > 0 ? g_waves_per_cu / LUTR_WPB : 1;
-    const int cap = (163840 / blocks_per_cu - tg->tab_bytes) / (16 * LUTR_WPB);   // nodes per wave: the CU's 160 KB over its resident blocks
-    if (tg->tab_bytes && tg->win_nodes > cap) tg->win_nodes = cap;
+    const int cap = (163840 / blocks_per_cu - tg->tab_bytes) / (kLN * LUTR_WPB);   // nodes per wave: the CU's 160 KB over its resident blocks
+    if (tg->win_nodes > cap) tg->win_nodes = cap;
     return tg->tab_bytes;
 }
 
@@ -1032,7 +1056,7 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
     const bool tab = plan_table(&tg, L) != 0;
-    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * 16;
+    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * kLN;
 #define RGB_CASE(W, I) \
     if (wide == W && mode == I) { \
         if (tab && L.unit) LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 2>), L, P, G, tg); \
@@ -1070,7 +1094,7 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
     const bool tab = plan_table(&tg, L) != 0;
-    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * 16;
+    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * kLN;
     const bool pre = K.pre != 0.0f;
     // ",unit" kernels drop both output clips: lattice in [0,1] (quantisation) and YUV maxima below max_o + 1
     const bool unit = L.unit && out_clip_dead(K, 1 << (csx + csy));
