@@ -22,6 +22,9 @@
 //                 construction, so the wait cannot deadlock) trails it.  One workgroup per (frame, plane).
 //                 This is latency-bound integer/float bookkeeping -- no roofline claim; it exists so that the
 //                 option does something, at a rate far above the CPU's.
+#include <mutex>
+#include <set>
+
 #include "lutr_device.h"
 
 namespace lutr {
@@ -229,11 +232,17 @@ const char *launch_yuv_dither(hipStream_t st, const LutConsts &L, const YuvConst
     if (nw > nbands) nw = nbands;
     const size_t lds = (size_t)nw * ((size_t)(G.w + 2) * sizeof(float) + sizeof(int));
     if (lds > 160 * 1024) return nullptr;                 // rows wider than ~40,000 samples: not supported
-    static bool attr_set = false;
-    if (!attr_set) {                                      // dynamic LDS above 64 KB has to be allowed per kernel
-        (void)hipFuncSetAttribute((const void *)k_dither_ed<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_dither_ed<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    {   // dynamic LDS above 64 KB has to be allowed per kernel and device
+        static std::set<int> done;
+        static std::mutex mu;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done.count(dev)) {
+            (void)hipFuncSetAttribute((const void *)k_dither_ed<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dither_ed<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done.insert(dev);
+        }
     }
     // packed path: every plane width a multiple of 4, destination rows aligned for 4-sample stores
     const int cwid = (G.w + (1 << csx) - 1) >> csx;

@@ -27,7 +27,9 @@
 // scalar C order, bit-identical to the oracle.
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <set>
+#include <utility>
 
 #include "lutr_internal.h"
 
@@ -950,18 +952,18 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
 }
 
 // ================================================================= launchers
-static int g_cus = 0;
-
+// Launchers may run on several threads at once (one context per thread): process-wide
+// state is initialised exactly once (function-local statics, call_once) or guarded by a mutex.
 static int device_cus()
 {
-    if (!g_cus) {
-        int dev = 0;
+    static const int cus = [] {
+        int dev = 0, n = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_cus = prop.multiProcessorCount;
-        if (g_cus <= 0) g_cus = 256;
-    }
-    return g_cus;
+            n = prop.multiProcessorCount;
+        return n > 0 ? n : 256;
+    }();
+    return cus;
 }
 
 // Split the 64 lanes of a wave between x (units of one row) and y (unit rows) so that a
@@ -1006,20 +1008,14 @@ static int tile_blocks(const TileGeom &tg, int waves_per_cu)
 
 static int g_win_nodes = 1024;       // 10 KB per wave, 40 KB per 256-thread block, 4 blocks per CU = all 160 KB
 static int g_waves_per_cu = 16;
-static bool g_env_read = false;
+static std::once_flag g_env_once;
 
 static void read_env_tuning()
 {
-    if (g_env_read) return;
-    g_env_read = true;
-    if (const char *e = getenv("LUTR_WIN_NODES")) { const int v = atoi(e); if (v >= 64 && v <= 2048) g_win_nodes = v; }
-    if (const char *e = getenv("LUTR_WAVES_PER_CU")) { const int v = atoi(e); if (v >= 4 && v <= 32) g_waves_per_cu = v; }
-}
-
-void tile_tuning(int win_nodes, int waves_per_cu)
-{
-    if (win_nodes >= 64) g_win_nodes = win_nodes;
-    if (waves_per_cu >= 4) g_waves_per_cu = waves_per_cu;
+    std::call_once(g_env_once, [] {
+        if (const char *e = getenv("LUTR_WIN_NODES")) { const int v = atoi(e); if (v >= 64 && v <= 2048) g_win_nodes = v; }
+        if (const char *e = getenv("LUTR_WAVES_PER_CU")) { const int v = atoi(e); if (v >= 4 && v <= 32) g_waves_per_cu = v; }
+    });
 }
 
 // The per-code coordinate table needs equal per-channel scales (one table serves R, G and B) and a
@@ -1038,10 +1034,15 @@ static int plan_table(TileGeom *tg, const LutConsts &L)
 // Blocks of more than 4 waves need more than the default 64 KB of dynamic LDS: allow it once per kernel.
 static void allow_lds(const void *kernel, size_t bytes)
 {
-    static std::set<const void *> done;
-    if (bytes <= 65536 || done.count(kernel)) return;
+    static std::set<std::pair<int, const void *>> done;      // the attribute is per device
+    static std::mutex mu;
+    if (bytes <= 65536) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return;
     (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done.insert(kernel);
+    done.insert({dev, kernel});
 }
 #define LUTR_LAUNCH_TILE(kernel, ...) \
     do { allow_lds((const void *)(kernel), lds); hipLaunchKernelGGL((kernel), grid, block, lds, st, __VA_ARGS__); } while (0)

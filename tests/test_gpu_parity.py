@@ -695,3 +695,39 @@ def test_randomised_differential_sweep(engine, orc, tmp_path):
             for fr in range(nf):
                 _assert_equal([g[fr]], [want[fr][i]], f"{what} plane {i} frame {fr} ({engine.last_kernel})")
     assert {"k_yuv_tile", "k_rgb_tile", "k_yuv_generic", "k_rgb_generic"} <= kernels, kernels
+
+
+def test_contexts_on_concurrent_threads(orc, cube_dir):
+    """The reference runs up to 16 TaskRunners at once (task_manager.py:229-235): one context per thread, all
+    launching concurrently, each on its own stream; every result must still be exact."""
+    import threading
+    from lut_renderer_amd.engine import LutEngine
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    k = orc.yuv_constants(din=10)
+    jobs = []
+    for t in range(6):
+        src = frames.natural_yuv(256, 64 + 16 * t, 10, 1, 1, k=20 + t)
+        jobs.append((src, orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src)))
+    errors = []
+
+    def work(i):
+        try:
+            src, want = jobs[i]
+            with LutEngine(0, use_torch_stream=False) as eng:          # the context's own stream
+                eng.set_lut(lut)
+                dev = [torch.from_numpy(p.view(np.int16)).to(eng.device) for p in src]
+                torch.cuda.synchronize()
+                for _ in range(20):
+                    out = eng.apply_yuv(dev, pix_fmt="yuv420p10le")
+                eng.sync()
+                got = [t.cpu().numpy().view(np.uint16) for t in out]
+                _assert_equal(got, want, f"thread {i}")
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
