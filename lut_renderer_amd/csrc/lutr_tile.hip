@@ -991,7 +991,9 @@ static void plan_tiles(TileGeom *tg, int uw, int urows, int nframes, int win_nod
     const int max_waves = device_cus() * waves_per_cu;
     int ch = 16;
     if (const char *e = getenv("LUTR_CHUNK")) { const int v = atoi(e); if (v >= 2 && v <= 256) ch = v; }
-    while (ch > 4 && (long long)nframes * tg->nsx * ((tg->nry + ch - 1) / ch) < max_waves / 2) ch >>= 1;
+    int shrink_div = 4;
+    if (const char *e = getenv("LUTR_SHRINK_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) shrink_div = v; }
+    while (ch > 1 && (long long)nframes * tg->nsx * ((tg->nry + ch - 1) / ch) < max_waves / shrink_div) ch >>= 1;
     tg->ch = ch;
     tg->nrc = (tg->nry + ch - 1) / ch;
     tg->nchunks = nframes * tg->nrc * tg->nsx;
