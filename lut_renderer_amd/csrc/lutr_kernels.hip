@@ -12,6 +12,8 @@
 //
 // This is gather + lerp: no MFMA.  The bound is HBM (6 B/px for yuv420p10le in+out)
 // and, before that, VALU issue; see DESIGN.md "Kernels".
+#include <cstdlib>
+
 #include "lutr_device.h"
 
 namespace lutr {
@@ -179,6 +181,17 @@ static bool planes_aligned(const PlaneSet &P, int plane, long long a, bool batch
     return true;
 }
 
+// The persistent tile kernels pay ~40 us before their first pixel is stored (coordinate table, first claim,
+// bounds pass, window staging) and win from ~5 UHD frames per launch upwards; below that the plain
+// 16-byte-vector kernels with taps gathered from L1/L2 finish sooner (one 1080p frame: 16 us against 48 us,
+// one UHD frame: 43 against 85; tools/latency_probe.py).  LUTR_SMALL_JOB_MPX moves the boundary (0 = never).
+static bool small_job(long long px)
+{
+    long long mpx = 40;
+    if (const char *e = getenv("LUTR_SMALL_JOB_MPX")) { const long long v = atoll(e); if (v >= 0 && v <= 100000) mpx = v; }
+    return px < mpx * 1000000ll;
+}
+
 static unsigned grid_for(long long units, unsigned cap = 0x7fffffffu)
 {
     long long b = (units + 255) / 256;
@@ -198,12 +211,12 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     for (int c = 0; c < 3 && vec_ok; c++)
         vec_ok = planes_aligned(P, c, 16, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
-    if (vec_ok && (variant == VAR_AUTO || variant == VAR_VEC_LDS))
+    if (vec_ok && ((variant == VAR_AUTO && !small_job(px)) || variant == VAR_VEC_LDS))
         return launch_rgb_tile(st, L, P, G, depth, mode, stats, queue);
     // A ragged width on aligned (padded) rows: the fast kernel takes the columns up to the last multiple of
     // its unit, the scalar kernel the few that remain (each pixel is independent, so any split is exact).
     const int wv = G.w / pxt * pxt;
-    if (variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w &&
+    if (variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w && !small_job(px) &&
         (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
         (long long)wv * G.rows * G.nframes / pxt < 0x7fffffffll &&
         planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, 16, G.nframes > 1) &&
@@ -251,12 +264,12 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     if (vec_ok) vec_ok = planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, cbytes, G.nframes > 1) &&
                          planes_aligned(P, 2, cbytes, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
-    if (vec_ok && (variant == VAR_AUTO || variant == VAR_VEC_LDS))
+    if (vec_ok && ((variant == VAR_AUTO && !small_job((long long)G.w * G.rows * G.nframes)) || variant == VAR_VEC_LDS))
         return launch_yuv_tile(st, L, K, P, G, win, csx, csy, mode, stats, queue);
     // ragged width on aligned (padded) rows: fast kernel up to the last whole unit, scalar kernel for the rest
     // (the split falls on a chroma-block boundary: the unit is 8 or 16 luma samples wide)
     const int wv = G.w / pxt * pxt;
-    if (variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w &&
+    if (variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w && !small_job((long long)G.w * G.rows * G.nframes) &&
         (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
         win == wout && G.row0 % bh == 0 && G.rows % bh == 0 && !(csx == 0 && csy == 1) &&
         (long long)(wv / pxt) * (G.rows >> csy) * G.nframes < 0x7fffffffll &&
