@@ -79,12 +79,15 @@ __global__ __launch_bounds__(256) void k_yuv_generic(LutConsts L, YuvConsts K, P
 }
 
 // ================================================================= vector kernels, global gather
-// 16-byte loads/stores per plane row: 8 px (16-bit containers) or 16 px (8-bit) per thread.
+// The low-latency path of small launches (and the A/B reference of the LDS window).  kVecBytes bytes per
+// plane row and thread: 4 px (16-bit containers) or 8 px (8-bit).  With 16-byte accesses these kernels needed
+// 256 VGPRs (one wave per SIMD); at 8 bytes they keep several waves per SIMD, which is what a gather wants.
+constexpr int kVecBytes = 8;
 
 template <int WIDE, int INTERP>
 __global__ __launch_bounds__(256) void k_rgb_vec(LutConsts L, PlaneSet P, FrameGeom G)
 {
-    constexpr int PXT = WIDE ? 8 : 16;
+    constexpr int PXT = kVecBytes / (WIDE ? 2 : 1), NW = kVecBytes / 4;
     const GFetch f(L);
     const unsigned uw = (unsigned)G.w / PXT;
     const unsigned total = uw * (unsigned)G.rows * (unsigned)G.nframes;
@@ -93,11 +96,13 @@ __global__ __launch_bounds__(256) void k_rgb_vec(LutConsts L, PlaneSet P, FrameG
     const unsigned xu = u % uw, t = u / uw;
     const int y = G.row0 + (int)(t % (unsigned)G.rows);
     const long long fr = t / (unsigned)G.rows;
-    const long long xo = (long long)xu * 16;
-    uint32_t gw[4], bw[4], rw[4], go[4] = {0, 0, 0, 0}, bo[4] = {0, 0, 0, 0}, ro[4] = {0, 0, 0, 0};
-    ld_words<4>(gw, P.s[0] + fr * P.sfs[0] + y * P.ss[0] + xo);
-    ld_words<4>(bw, P.s[1] + fr * P.sfs[1] + y * P.ss[1] + xo);
-    ld_words<4>(rw, P.s[2] + fr * P.sfs[2] + y * P.ss[2] + xo);
+    const long long xo = (long long)xu * kVecBytes;
+    uint32_t gw[NW], bw[NW], rw[NW], go[NW], bo[NW], ro[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) { go[k] = 0; bo[k] = 0; ro[k] = 0; }
+    ld_words<NW>(gw, P.s[0] + fr * P.sfs[0] + y * P.ss[0] + xo);
+    ld_words<NW>(bw, P.s[1] + fr * P.sfs[1] + y * P.ss[1] + xo);
+    ld_words<NW>(rw, P.s[2] + fr * P.sfs[2] + y * P.ss[2] + xo);
 #pragma unroll
     for (int i = 0; i < PXT; i++) {
         const Rgb o = lut3d_px<INTERP>(L, f, word_sample<WIDE>(rw, i), word_sample<WIDE>(gw, i),
@@ -106,18 +111,20 @@ __global__ __launch_bounds__(256) void k_rgb_vec(LutConsts L, PlaneSet P, FrameG
         word_put<WIDE>(bo, i, o.b);
         word_put<WIDE>(ro, i, o.r);
     }
-    st_words<4>(P.d[0] + fr * P.dfs[0] + y * P.ds[0] + xo, go);
-    st_words<4>(P.d[1] + fr * P.dfs[1] + y * P.ds[1] + xo, bo);
-    st_words<4>(P.d[2] + fr * P.dfs[2] + y * P.ds[2] + xo, ro);
+    st_words<NW>(P.d[0] + fr * P.dfs[0] + y * P.ds[0] + xo, go);
+    st_words<NW>(P.d[1] + fr * P.dfs[1] + y * P.ds[1] + xo, bo);
+    st_words<NW>(P.d[2] + fr * P.dfs[2] + y * P.ds[2] + xo, ro);
 }
 
 template <int WIDE, int CSX, int CSY, int INTERP>
 __global__ __launch_bounds__(256) void k_yuv_vec(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G)
 {
-    constexpr int PXT = WIDE ? 8 : 16;                    // luma samples per thread per row
+    constexpr int PXT = kVecBytes / (WIDE ? 2 : 1);       // luma samples per thread per row
+    constexpr int YW = kVecBytes / 4;                     // luma words per thread per row
     constexpr int BH = 1 << CSY, BW = 1 << CSX;
     constexpr int NC = PXT >> CSX;                        // chroma samples per thread
-    constexpr int CW = NC * (WIDE ? 2 : 1) / 4;           // chroma words per thread (2 or 4)
+    constexpr int CW = NC * (WIDE ? 2 : 1) / 4;           // chroma words per thread (1 or 2)
+    static_assert(CW >= 1, "a thread must own whole chroma words");
     const GFetch f(L);
     const unsigned uw = (unsigned)G.w / PXT;
     const unsigned ub = (unsigned)G.rows >> CSY;
@@ -127,15 +134,15 @@ __global__ __launch_bounds__(256) void k_yuv_vec(LutConsts L, YuvConsts K, Plane
     const unsigned xu = u % uw, t = u / uw;
     const int cy = (G.row0 >> CSY) + (int)(t % ub);
     const long long fr = t / ub;
-    const long long xo = (long long)xu * 16, cxo = (long long)xu * (CW * 4);
+    const long long xo = (long long)xu * kVecBytes, cxo = (long long)xu * (CW * 4);
 
-    uint32_t yw[BH][4], cbw[CW], crw[CW];
-    uint32_t yo[BH][4], cbo[CW], cro[CW];
+    uint32_t yw[BH][YW], cbw[CW], crw[CW];
+    uint32_t yo[BH][YW], cbo[CW], cro[CW];
 #pragma unroll
     for (int dy = 0; dy < BH; dy++) {
-        ld_words<4>(yw[dy], P.s[0] + fr * P.sfs[0] + (long long)(cy * BH + dy) * P.ss[0] + xo);
+        ld_words<YW>(yw[dy], P.s[0] + fr * P.sfs[0] + (long long)(cy * BH + dy) * P.ss[0] + xo);
 #pragma unroll
-        for (int k = 0; k < 4; k++) yo[dy][k] = 0;
+        for (int k = 0; k < YW; k++) yo[dy][k] = 0;
     }
     ld_words<CW>(cbw, P.s[1] + fr * P.sfs[1] + (long long)cy * P.ss[1] + cxo);
     ld_words<CW>(crw, P.s[2] + fr * P.sfs[2] + (long long)cy * P.ss[2] + cxo);
@@ -159,10 +166,18 @@ __global__ __launch_bounds__(256) void k_yuv_vec(LutConsts L, YuvConsts K, Plane
         }
         word_put<WIDE>(cbo, j, rgb_to_cb(K, rs, gs, bs));
         word_put<WIDE>(cro, j, rgb_to_cr(K, rs, gs, bs));
+        // Zero-instruction fence: without it hipcc hoists the coordinates and taps of every chroma block of the
+        // thread to the top (256 VGPRs, one wave per SIMD); with it blocks are emitted one after the other.
+#pragma unroll
+        for (int dy = 0; dy < BH; dy++)
+#pragma unroll
+            for (int k = 0; k < YW; k++) asm volatile("" : "+v"(yw[dy][k]), "+v"(yo[dy][k]));
+#pragma unroll
+        for (int k = 0; k < CW; k++) asm volatile("" : "+v"(cbw[k]), "+v"(crw[k]), "+v"(cbo[k]), "+v"(cro[k]));
     }
 #pragma unroll
     for (int dy = 0; dy < BH; dy++)
-        st_words<4>(P.d[0] + fr * P.dfs[0] + (long long)(cy * BH + dy) * P.ds[0] + xo, yo[dy]);
+        st_words<YW>(P.d[0] + fr * P.dfs[0] + (long long)(cy * BH + dy) * P.ds[0] + xo, yo[dy]);
     st_words<CW>(P.d[1] + fr * P.dfs[1] + (long long)cy * P.ds[1] + cxo, cbo);
     st_words<CW>(P.d[2] + fr * P.dfs[2] + (long long)cy * P.ds[2] + cxo, cro);
 }
@@ -182,12 +197,14 @@ static bool planes_aligned(const PlaneSet &P, int plane, long long a, bool batch
 }
 
 // The persistent tile kernels pay ~40 us before their first pixel is stored (coordinate table, first claim,
-// bounds pass, window staging) and win from ~5 UHD frames per launch upwards; below that the plain
-// 16-byte-vector kernels with taps gathered from L1/L2 finish sooner (one 1080p frame: 16 us against 48 us,
-// one UHD frame: 43 against 85; tools/latency_probe.py).  LUTR_SMALL_JOB_MPX moves the boundary (0 = never).
+// bounds pass, window staging) and end with a ~100 us tail of partly idle CUs, so they only win on big launches:
+// 16 UHD frames take 379 us on them and 382 us on the plain vector kernels (taps gathered from L1/L2, 5-8 waves
+// per SIMD), 64 frames 1083 us against 1537 us, but one UHD frame 85 us against 25 us and one 1080p frame
+// 48 us against 17 us (tools/latency_probe.py, bench.py --frames N --variant ...).  "auto" therefore sends
+// launches under 130 Mpx to the vector kernels.  LUTR_SMALL_JOB_MPX moves the boundary (0 = never).
 static bool small_job(long long px)
 {
-    long long mpx = 40;
+    long long mpx = 130;
     if (const char *e = getenv("LUTR_SMALL_JOB_MPX")) { const long long v = atoll(e); if (v >= 0 && v <= 100000) mpx = v; }
     return px < mpx * 1000000ll;
 }
@@ -237,7 +254,7 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
         hipLaunchKernelGGL(k_rgb_generic, dim3(grid_for(px, 256 * 64)), dim3(256), 0, st, L, P, G, wide, mode);
         return "k_rgb_generic";
     }
-    const dim3 grid(grid_for(px / pxt)), block(256);
+    const dim3 grid(grid_for(px / (kVecBytes / (wide ? 2 : 1)))), block(256);
 #define RGB_CASE(W, I) \
     if (wide == W && mode == I) { \
         hipLaunchKernelGGL((k_rgb_vec<W, I>), grid, block, 0, st, L, P, G); \
@@ -295,7 +312,7 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
                            csx, csy, mode);
         return "k_yuv_generic";
     }
-    const long long units = (long long)(G.w / pxt) * (G.rows >> csy) * G.nframes;
+    const long long units = (long long)(G.w / (kVecBytes / (win ? 2 : 1))) * (G.rows >> csy) * G.nframes;
     const dim3 grid(grid_for(units)), block(256);
 #define YUV_CASE(W, X, Y, I) \
     if (win == W && csx == X && csy == Y && mode == I) { \
