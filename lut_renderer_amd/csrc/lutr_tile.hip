@@ -651,12 +651,9 @@ __device__ __forceinline__ void yuv_tile_bounds(const LutConsts &L, const YuvCon
 #define LUTR_TILE_WAVES_PER_EU 4
 #endif
 
-// Claim the next chunk for this wave; returns false when the queue is drained.
-__device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &fr, int &sx, int &ry, int &rem)
+// Position of chunk c on the batch; false when c is past the end.
+__device__ __forceinline__ bool chunk_at(const TileGeom &TG, unsigned c, int &fr, int &sx, int &ry, int &rem)
 {
-    unsigned c = 0;
-    if (lane == 0) c = atomicAdd(TG.queue, 1u);
-    c = (unsigned)uni((int)c);
     if (c >= (unsigned)TG.nchunks) return false;
     const int per_frame = TG.nrc * TG.nsx;
     fr = (int)c / per_frame;
@@ -666,6 +663,27 @@ __device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &f
     ry = rc * TG.ch;
     rem = min(TG.ch, TG.nry - ry);
     return true;
+}
+
+// Claim the next chunk for this wave; returns false when the queue is drained.  The queue counter starts at
+// LUTR_STATIC_ROUNDS x the number of waves in the grid: wave w takes chunks w, w + waves, ... as its first ones
+// without an atomic (4096 atomics on one address at kernel start serialise in the L2 for ~50 us before the
+// last wave has work, and the waves are still in step when they finish their first chunk).
+#ifndef LUTR_STATIC_ROUNDS
+#define LUTR_STATIC_ROUNDS 1
+#endif
+__device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &fr, int &sx, int &ry, int &rem, int &round)
+{
+    unsigned c = 0;
+    if (round < LUTR_STATIC_ROUNDS) {
+        c = (unsigned)(round * (int)(gridDim.x * LUTR_WPB) + (int)(blockIdx.x * LUTR_WPB) + uni((int)(threadIdx.x >> 6)));
+        round++;
+        if (c < (unsigned)TG.nchunks) return chunk_at(TG, c, fr, sx, ry, rem);
+        round = LUTR_STATIC_ROUNDS;          // the static share is used up: continue with the queue
+    }
+    if (lane == 0) c = atomicAdd(TG.queue, 1u);
+    c = (unsigned)uni((int)c);
+    return chunk_at(TG, c, fr, sx, ry, rem);
 }
 
 template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
@@ -686,7 +704,8 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
     const int wave = blockIdx.x * LUTR_WPB + wib;
     const int slice_off = TG.tab_bytes + wib * TG.win_nodes * kLN;
     int fr, sx, ry, rem;                                      // the tile being fetched next
-    if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
+    int round = 0;
+    if (!claim_chunk(TG, lane, fr, sx, ry, rem, round)) return;   // wave-uniform; the first chunks go by wave id
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
@@ -728,7 +747,7 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
         // simply fetched again, so every path has the same number of memory operations in flight and
         // hipcc can wait with a counted vmcnt instead of vmcnt(0).
         if (--rem > 0) ry++;
-        else { more = claim_chunk(TG, lane, fr, sx, ry, rem); nxt_fresh = true; }
+        else { more = claim_chunk(TG, lane, fr, sx, ry, rem, round); nxt_fresh = true; }
         load_tile(nxt, fr, sx, ry);
 
         T out;
@@ -877,7 +896,8 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
     const int wib = uni(threadIdx.x >> 6);
     const int slice_off = TG.tab_bytes + wib * TG.win_nodes * kLN;
     int fr, sx, ry, rem;                                      // the tile being fetched next
-    if (!claim_chunk(TG, lane, fr, sx, ry, rem)) return;      // wave-uniform; no barrier is ever used
+    int round = 0;
+    if (!claim_chunk(TG, lane, fr, sx, ry, rem, round)) return;   // wave-uniform; the first chunks go by wave id
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
 
@@ -906,7 +926,7 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
         nxt_fresh = false;
         const int cfr = fr, csx = sx, cry = ry;
         if (--rem > 0) ry++;                    // next tile of the chunk, or a new chunk (see k_yuv_tile)
-        else { more = claim_chunk(TG, lane, fr, sx, ry, rem); nxt_fresh = true; }
+        else { more = claim_chunk(TG, lane, fr, sx, ry, rem, round); nxt_fresh = true; }
         load_tile(nxt, fr, sx, ry);
 
         T out;
@@ -1056,8 +1076,9 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     TileGeom tg;
     read_env_tuning();
     plan_tiles(&tg, G.w / pxt, G.rows, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
-    if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
+    // the queue starts behind the chunks the waves take by their id (claim_chunk)
+    if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_WPB * LUTR_STATIC_ROUNDS), 1, st) != hipSuccess) return nullptr;
     const bool tab = plan_table(&tg, L) != 0;
     const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * kLN;
 #define RGB_CASE(W, I) \
@@ -1094,8 +1115,9 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     TileGeom tg;
     read_env_tuning();
     plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
-    if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
+    // the queue starts behind the chunks the waves take by their id (claim_chunk)
+    if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_WPB * LUTR_STATIC_ROUNDS), 1, st) != hipSuccess) return nullptr;
     const bool tab = plan_table(&tg, L) != 0;
     const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * kLN;
     const bool pre = K.pre != 0.0f;
