@@ -734,7 +734,7 @@ def test_contexts_on_concurrent_threads(orc, cube_dir):
 
 
 def test_small_jobs_take_the_low_latency_kernels(engine, orc, cube_dir, monkeypatch):
-    """Under "auto" a launch below the small-job boundary (130 Mpx by default) runs on the plain vector kernels
+    """Under "auto" a launch below the small-job boundary (95 Mpx by default) runs on the plain vector kernels
     (3x lower latency for one 1080p frame), anything larger on the tile kernels; same pixels either way."""
     lut = _load(engine, cube_dir, "log709_33.cube")
     src = frames.natural_yuv(512, 128, 10, 1, 1, k=5)
@@ -742,7 +742,7 @@ def test_small_jobs_take_the_low_latency_kernels(engine, orc, cube_dir, monkeypa
     k = orc.yuv_constants(din=10)
     want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src)
     want_rgb = orc.apply_rgb(lut.table, lut.scale, 10, "tetrahedral", rgb)
-    for mpx, expect in (("130", "k_yuv_vec"), ("0", "k_yuv_tile")):
+    for mpx, expect in (("95", "k_yuv_vec"), ("0", "k_yuv_tile")):
         monkeypatch.setenv("LUTR_SMALL_JOB_MPX", mpx)
         got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le")
         assert engine.last_kernel.startswith(expect), engine.last_kernel
