@@ -7,7 +7,7 @@
 
 A "step" is one pass of the fused kernel over a batch of synthetic frames that is already
 resident in HBM.  Default workload = BASELINE.json configs[1]: 3840x2160 yuv420p10le,
-33^3 log->Rec.709 .cube, tetrahedral, 1 GPU.  With N > 1 every frame is split into N row
+33^3 log->Rec.709 .cube, tetrahedral, 1 GPU, 256 frames per launch (12.7 GB of the 288 GB HBM).  With N > 1 every frame is split into N row
 blocks; rank g owns block g of N x FRAMES frames, so per-GPU work is fixed
 ("weak" scaling); the only collective is the RCCL broadcast of the lattice at LUT load.
 
@@ -45,7 +45,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (SURVEY 8d: >= 64)")
+    ap.add_argument("--frames", type=int, default=256,
+                    help="frames per GPU per step (SURVEY 8d: >= 64; 256 = the batch of BASELINE config 5: 6.4 GB in + 6.4 GB out)")
     ap.add_argument("--size", default="uhd", choices=sorted(SIZES))
     ap.add_argument("--fmt", default="yuv420p10le")
     ap.add_argument("--interp", default="tetrahedral")
