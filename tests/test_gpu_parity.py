@@ -660,7 +660,7 @@ def test_randomised_differential_sweep(engine, orc, tmp_path):
         else:
             fr_np = [frames.make_yuv("uniform" if rng.random() < 0.5 else "natural", w, h, pf.depth, pf.csx, pf.csy,
                                      k=case * 7 + i) for i in range(nf)]
-        src, dst = [], []
+        src, dst, guards = [], [], []
         for i in range(3):
             ph, pw = pf.plane_shape(i, w, h)
             stride = ((pw * esz + 63) // 64) * 64 // esz if padded else pw
@@ -668,7 +668,10 @@ def test_randomised_differential_sweep(engine, orc, tmp_path):
             arr = np.stack([f[i] for f in fr_np])
             buf[:, :, :pw] = torch.from_numpy(arr.view(np.int16) if esz == 2 else arr).to(engine.device)
             src.append(buf[:, :, :pw])
-            dst.append(torch.zeros_like(buf)[:, :, :pw])
+            # destination with a guard row above and below every frame and (when padded) guard columns to the right
+            guard = torch.full((nf, ph + 2, stride), 0x5A5A if esz == 2 else 0x5A, dtype=tdt, device=engine.device)
+            guards.append(guard)
+            dst.append(guard[:, 1:ph + 1, :pw])
         what = f"case {case}: {fmt} {w}x{h}x{nf} N={n} {mode} padded={padded}"
         if pf.family == "gbr":
             got = engine.apply_rgb(src, dst, depth=pf.depth, interp=mode)
@@ -689,6 +692,11 @@ def test_randomised_differential_sweep(engine, orc, tmp_path):
             want = [orc.apply_yuv(tab, scale, mode, k, pf.depth, pf.depth, pf.depth, pf.csx, pf.csy, f) for f in fr_np]
             what += f" {m_in}->{m_out} {r_out} shard={shard}"
         kernels.add(engine.last_kernel.split("<")[0])
+        for i in range(3):                                                      # nothing outside the planes was written
+            ph, pw = pf.plane_shape(i, w, h)
+            gv = 0x5A5A if esz == 2 else 0x5A
+            assert (guards[i][:, 0, :] == gv).all() and (guards[i][:, ph + 1, :] == gv).all(), what + " guard rows"
+            assert (guards[i][:, :, pw:] == gv).all(), what + " guard columns"
         for i in range(3):
             g = got[i].cpu().numpy()
             g = g.view(np.uint16) if esz == 2 else g
