@@ -1,0 +1,57 @@
+"""An independent third-party 3D LUT against the oracle (CPU).
+
+FFmpeg itself is not on this image, so the oracle's lut3d restatement stays unpinned.  Pillow
+ships its own trilinear 3D LUT (`ImageFilter.Color3DLUT`, fixed-point C code unrelated to FFmpeg's).  It cannot
+pin FFmpeg's float arithmetic -- its rounding differs -- but it does check what a transcription error would
+break: the axis order of the lattice (which channel varies fastest), the cell/fraction computation and the
+blend.  Agreement within 1 code on 8-bit data is what two correct trilinear implementations give.
+"""
+import numpy as np
+import pytest
+
+
+PIL = pytest.importorskip("PIL")
+from PIL import Image, ImageFilter  # noqa: E402
+
+
+def _pillow_apply(table, img):
+    n = table.shape[0]
+    # Pillow wants r varying fastest: index ((b * n + g) * n + r); ours is table[r, g, b]
+    flat = np.ascontiguousarray(np.transpose(table, (2, 1, 0, 3))).reshape(-1).astype(np.float32)
+    lut = ImageFilter.Color3DLUT(n, flat.tolist(), channels=3, target_mode="RGB")
+    return np.asarray(Image.fromarray(img, "RGB").filter(lut))
+
+
+def _smooth_lattice(n):
+    """Gamma-like curves with cross-channel terms: every output depends on two inputs, asymmetrically, so any
+    swap of axes or channels shows up; smooth enough that Pillow's fixed-point weights cost less than a code."""
+    g = np.linspace(0, 1, n, dtype=np.float32)
+    r, gg, b = np.meshgrid(g, g, g, indexing="ij")
+    return np.stack([np.clip(r ** 0.8 * 0.85 + 0.15 * b, 0, 1), np.clip(gg ** 1.1 * 0.9 + 0.05 * r, 0, 1),
+                     np.clip(b * 0.7 + 0.3 * gg ** 2, 0, 1)], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [9, 17, 33])
+def test_trilinear_agrees_with_pillow_within_one_code(orc, n):
+    rng = np.random.default_rng(n)
+    table = _smooth_lattice(n)
+    img = rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)
+    want = _pillow_apply(table, img).astype(np.int32)
+    got = orc.apply_packed(table, np.ones(3, np.float32), "rgb24", "trilinear", img).astype(np.int32)
+    diff = np.abs(got - want)
+    assert diff.max() <= 1, (int(diff.max()), np.argwhere(diff > 1)[:3])
+    # the oracle truncates like FFmpeg, Pillow rounds: the oracle is equal or exactly one below, never above
+    assert (got <= want).all()
+    # tetrahedral is a different interpolant but stays close on a smooth lattice
+    tet = orc.apply_packed(table, np.ones(3, np.float32), "rgb24", "tetrahedral", img).astype(np.int32)
+    assert np.abs(tet - want).max() <= 2
+
+
+def test_axis_swap_would_be_caught(orc):
+    """Sanity of the check itself: feeding Pillow the lattice with R and B axes swapped disagrees by far more."""
+    n = 17
+    table = _smooth_lattice(n)
+    img = np.random.default_rng(1).integers(0, 256, size=(16, 16, 3), dtype=np.uint8)
+    good = orc.apply_packed(table, np.ones(3, np.float32), "rgb24", "trilinear", img).astype(np.int32)
+    swapped = _pillow_apply(np.transpose(table, (2, 1, 0, 3)), img).astype(np.int32)
+    assert np.abs(good - swapped).max() > 20
