@@ -55,3 +55,23 @@ def test_axis_swap_would_be_caught(orc):
     good = orc.apply_packed(table, np.ones(3, np.float32), "rgb24", "trilinear", img).astype(np.int32)
     swapped = _pillow_apply(np.transpose(table, (2, 1, 0, 3)), img).astype(np.int32)
     assert np.abs(good - swapped).max() > 20
+
+
+def test_trilinear_agrees_with_scipy_in_double_precision(orc):
+    """SciPy's RegularGridInterpolator (linear) is trilinear interpolation in float64: at 10 bit the oracle's
+    (int)(v * 1023) must equal floor of the double-precision value except where fp32 rounding flips an exact
+    boundary (a fraction of a percent, never more than one code)."""
+    interp = pytest.importorskip("scipy.interpolate")
+    n = 17
+    table = _smooth_lattice(n)
+    rng = np.random.default_rng(3)
+    planes = [rng.integers(0, 1024, size=(40, 50), dtype=np.uint16) for _ in range(3)]        # G, B, R
+    g, b, r = orc.apply_rgb(table, np.ones(3, np.float32), 10, "trilinear", planes)
+    grid = np.linspace(0.0, 1.0, n)
+    pts = np.stack([planes[2].ravel(), planes[0].ravel(), planes[1].ravel()], -1) / 1023.0     # (r, g, b) in [0, 1]
+    for ch, got in enumerate((r, g, b)):
+        f = interp.RegularGridInterpolator((grid, grid, grid), table[..., ch].astype(np.float64), method="linear")
+        want = np.floor(f(pts) * 1023.0 + 1e-9).reshape(got.shape)
+        diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        assert diff.max() <= 1
+        assert (diff == 0).mean() > 0.99, (ch, (diff == 0).mean())
