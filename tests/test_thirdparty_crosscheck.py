@@ -75,3 +75,30 @@ def test_trilinear_agrees_with_scipy_in_double_precision(orc):
         diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
         assert diff.max() <= 1
         assert (diff == 0).mean() > 0.99, (ch, (diff == 0).mean())
+
+
+def test_yuv_matrices_match_the_published_studio_swing_coefficients(orc):
+    """The YUV contract's constants against the textbook 8-bit studio-range equations of BT.709 and BT.601
+    (ITU-R BT.709-6 / BT.601-7 as usually tabulated to three decimals), and the classic colour-bar codes."""
+    k709 = orc.yuv_constants("bt709", "tv", "bt709", "tv", 8, 8, 8, 1)
+    # R = 1.164 (Y-16) + 1.793 (Cr-128);  G = 1.164 (Y-16) - 0.213 (Cb-128) - 0.533 (Cr-128);  B = 1.164 (Y-16) + 2.112 (Cb-128)
+    assert (round(k709.ky, 3), round(k709.krv, 3), round(k709.kgu, 3), round(k709.kgv, 3), round(k709.kbu, 3)) == \
+        (1.164, 1.793, -0.213, -0.533, 2.112)
+    # Y = 16 + 0.183 R + 0.614 G + 0.062 B;  Cb = 128 - 0.101 R - 0.339 G + 0.439 B;  Cr = 128 + 0.439 R - 0.399 G - 0.040 B
+    got = [round(v, 3) for v in (k709.cyr, k709.cyg, k709.cyb, k709.cbr, k709.cbg, k709.cbb, k709.crr, k709.crg, k709.crb)]
+    assert got == [0.183, 0.614, 0.062, -0.101, -0.339, 0.439, 0.439, -0.399, -0.040]
+    k601 = orc.yuv_constants("smpte170m", "tv", "smpte170m", "tv", 8, 8, 8, 1)
+    # R = 1.164 (Y-16) + 1.596 (Cr-128);  G = ... - 0.392 (Cb-128) - 0.813 (Cr-128);  B = ... + 2.017 (Cb-128)
+    assert (round(k601.krv, 3), round(k601.kgu, 3), round(k601.kgv, 3), round(k601.kbu, 3)) == (1.596, -0.392, -0.813, 2.017)
+    got = [round(v, 3) for v in (k601.cyr, k601.cyg, k601.cyb, k601.cbr, k601.cbg, k601.cbb, k601.crr, k601.crg, k601.crb)]
+    assert got == [0.257, 0.504, 0.098, -0.148, -0.291, 0.439, 0.439, -0.368, -0.071]
+    # 100 % colour bars through the full path with an identity lattice: 8-bit BT.709 codes (Y, Cb, Cr)
+    from lut_renderer_amd import cube
+    ident = cube.identity_lattice(33)
+    bars = {"white": (235, 128, 128), "black": (16, 128, 128), "red": (63, 102, 240), "green": (173, 42, 26),
+            "blue": (32, 240, 118), "yellow": (219, 16, 138), "cyan": (188, 154, 16), "magenta": (78, 214, 230)}
+    for name, (y, cb, cr) in bars.items():
+        src = [np.full((2, 2), y, np.uint8), np.full((2, 2), cb, np.uint8), np.full((2, 2), cr, np.uint8)]
+        out = orc.apply_yuv(ident, np.ones(3, np.float32), "trilinear", k709, 8, 8, 8, 0, 0, src)
+        got = tuple(int(p[0, 0]) for p in out)
+        assert all(abs(a - b) <= 1 for a, b in zip(got, (y, cb, cr))), (name, got)
