@@ -92,6 +92,10 @@ def test_yuv_matrices_match_the_published_studio_swing_coefficients(orc):
     assert (round(k601.krv, 3), round(k601.kgu, 3), round(k601.kgv, 3), round(k601.kbu, 3)) == (1.596, -0.392, -0.813, 2.017)
     got = [round(v, 3) for v in (k601.cyr, k601.cyg, k601.cyb, k601.cbr, k601.cbg, k601.cbb, k601.crr, k601.crg, k601.crb)]
     assert got == [0.257, 0.504, 0.098, -0.148, -0.291, 0.439, 0.439, -0.368, -0.071]
+    k2020 = orc.yuv_constants("bt2020nc", "tv", "bt2020nc", "tv", 8, 8, 8, 1)
+    # BT.2020 NCL: R = 1.164 (Y-16) + 1.679 (Cr-128);  G = ... - 0.187 (Cb-128) - 0.650 (Cr-128);  B = ... + 2.142 (Cb-128)
+    assert (round(k2020.krv, 3), round(k2020.kgu, 3), round(k2020.kgv, 3), round(k2020.kbu, 3)) == (1.679, -0.187, -0.650, 2.142)
+    assert [round(v * 255 / 219, 4) for v in (k2020.cyr, k2020.cyg, k2020.cyb)] == [0.2627, 0.6780, 0.0593]
     # 100 % colour bars through the full path with an identity lattice: 8-bit BT.709 codes (Y, Cb, Cr)
     from lut_renderer_amd import cube
     ident = cube.identity_lattice(33)
