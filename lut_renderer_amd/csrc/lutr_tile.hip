@@ -1000,6 +1000,7 @@ static void plan_tiles(TileGeom *tg, int uw, int urows, int nframes, int win_nod
         const double eff = ((double)uw / (((uw + lw - 1) / lw) * lw)) * ((double)urows / (((urows + lh - 1) / lh) * lh));
         if (eff > best_eff + 0.02) { best_eff = eff; best = l; }
     }
+    if (const char *e = getenv("LUTR_LW_LOG2")) { const int v = atoi(e); if (v >= 2 && v <= 6) best = v; }
     tg->lw_log2 = best;
     tg->uw = uw;
     tg->urows = urows;
