@@ -283,24 +283,41 @@ def main():
                 del s2
 
     host_pipe = None
-    if args.pipeline == "host" and rank == 0 and pf.family == "yuv":
+    if args.pipeline == "host" and pf.family == "yuv":
+        # BASELINE config 5: frames queued in pinned host memory, round-robin over the GPUs (whole frames per rank,
+        # every rank drives its own 3-slot ring); total = all ranks' frames / the slowest rank's time
+        from lut_renderer_amd import frames as _frames
         from lut_renderer_amd.stream import HostPipeline
         pipe = HostPipeline(eng, args.fmt, w, h, batch=8, slots=3, interp=args.interp)
-        one = b"".join(np.ascontiguousarray(t[0].cpu().numpy()).tobytes() for t in src)
+        full = _frames.make_yuv(args.dist, w, h, pf.depth, pf.csx, pf.csy, k=0)
+        one = b"".join(np.ascontiguousarray(p).tobytes() for p in full)
         for sl in range(pipe.slots):                 # inputs pre-filled: the producer is not what is measured
             pipe.host_in(sl)[:] = np.frombuffer(one * pipe.batch, dtype=np.uint8)
+        mine = args.host_frames // world + (1 if rank < args.host_frames % world else 0)
         pipe.run(lambda b, m: m, lambda b, k: None, total_frames=24)        # warm-up
         torch.cuda.synchronize()
+        barrier(world)
         t0 = time.perf_counter()
-        n_done = pipe.run(lambda b, m: m, lambda b, k: None, total_frames=args.host_frames)
+        n_done = pipe.run(lambda b, m: m, lambda b, k: None, total_frames=mine)
         torch.cuda.synchronize()
+        barrier(world)
         el = time.perf_counter() - t0
-        gb = n_done * (pipe.fin.frame_bytes + pipe.fout.frame_bytes) / 1e9
-        host_pipe = {"frames": n_done, "fps": round(n_done / el, 1), "Mpixels_s": round(n_done * w * h / el / 1e6, 1),
-                     "pcie_GBps_each_way": round(gb / 2 / el, 1),
-                     "note": "frames in pinned host memory, 3-slot ring of 8-frame batches, H2D / kernel / D2H on "
-                             "separate streams; PCIe Gen5 x16-bound (63 GB/s per direction spec)"}
-        log(f"[host pipeline] {host_pipe}")
+        tot = torch.tensor([float(n_done)], dtype=torch.float64, device=eng.device)
+        if world > 1:
+            import torch.distributed as dist
+            te = torch.tensor([el], dtype=torch.float64, device=eng.device)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            el = te.item()
+        n_all = int(tot.item())
+        gb = n_all * (pipe.fin.frame_bytes + pipe.fout.frame_bytes) / 1e9
+        host_pipe = {"frames": n_all, "fps": round(n_all / el, 1), "Mpixels_s": round(n_all * w * h / el / 1e6, 1),
+                     "pcie_GBps_each_way": round(gb / 2 / el, 1), "gpus": world,
+                     "note": "frames in pinned host memory, round-robin over the GPUs, per GPU a 3-slot ring of 8-frame "
+                             "batches with H2D / kernel / D2H on separate streams; PCIe Gen5 x16-bound (63 GB/s per "
+                             "direction and GPU by spec); pcie_GBps_each_way is the sum over GPUs"}
+        if rank == 0:
+            log(f"[host pipeline] {host_pipe}")
     if rank == 0:
         bpp_in = (float(pf.nc) if pf.family == "packed" else 3.0 if pf.family == "gbr"
                   else 1.0 + 2.0 / (1 << (pf.csx + pf.csy))) * (1 if pf.depth <= 8 else 2)

@@ -532,13 +532,15 @@ def test_bench_two_ranks_rehearsal():
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     res = _torchrun(2, [str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "2",
-                        "--size", "1080p"], {})
+                        "--size", "1080p", "--pipeline", "host", "--host-frames", "20"], {})
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["config"]["parallelism"] == "row-block x2" and "tile" in d["config"]["kernel"]
+    # BASELINE config 5 over the ranks: whole frames round-robin, every rank drives its own pinned ring
+    assert d["host_pipeline"]["gpus"] == 2 and d["host_pipeline"]["frames"] == 20 and d["host_pipeline"]["fps"] > 0
 
 
 @pytest.mark.parametrize("fmt,out_fmt,w,h,nframes", [
