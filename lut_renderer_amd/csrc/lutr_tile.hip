@@ -87,14 +87,28 @@ struct Win {
 // A compile-time constant lets the +1-blue taps use the immediate offset field of ds_read / global_load.
 constexpr int kOB = 16;
 // Bytes per node in an LDS window: 16 (the global float4 node, one ds_read_b128 per tap) or 12 ({r,g,b} only:
-// a third more nodes per wave, a tap = ds_read2_b32 + ds_read_b32).  Measured on the headline workload: 12-byte
-// nodes cut the gather tiles by a third (20,416 -> 13,728 of 518,400) and need 6 fewer VGPRs, but the extra LDS
-// instructions and cycles cost as much as that saves (487 vs 491 Gpx/s), so 16 stays.
-#ifndef LUTR_LDS_NODE
-#define LUTR_LDS_NODE 16
+// a third more nodes per wave, a tap = ds_read2_b32 + ds_read_b32, 3 registers instead of 4).  The 4-tap
+// modes take 12: a third fewer tiles fall back to the gather body (20,416 -> 13,728 of 518,400 on the headline
+// workload) and the 6 VGPRs it frees hold three more per-pixel constants (LUTR_PIN_MORE), together +3.5 %;
+// the 8-tap trilinear body keeps 16 (16 LDS instructions per pixel would cost more than the window gains).
+// LUTR_LDS_NODE forces one size for every mode (experiments).
+template <int INTERP> constexpr int lds_node()
+{
+#ifdef LUTR_LDS_NODE
+    return LUTR_LDS_NODE;
+#else
+    return INTERP == LUTR_INTERP_TRILINEAR ? 16 : 12;
 #endif
-constexpr int kLN = LUTR_LDS_NODE;
-template <bool LDS> constexpr int node_b() { return LDS ? kLN : kOB; }
+}
+static inline int lds_node_rt(int mode)
+{
+#ifdef LUTR_LDS_NODE
+    return LUTR_LDS_NODE;
+#else
+    return mode == LUTR_INTERP_TRILINEAR ? 16 : 12;
+#endif
+}
+template <bool LDS, int INTERP> constexpr int node_b() { return LDS ? lds_node<INTERP>() : kOB; }
 
 struct Bnd { float rmin, rmax, gmin, gmax, bmin, bmax; };
 
@@ -151,10 +165,10 @@ __device__ __forceinline__ int lds_base()
     return (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lutr_smem;
 }
 
-template <bool LDS>
+template <bool LDS, int NODE = 16>
 __device__ __forceinline__ f4 tap(const float4 *__restrict__ lat, int a)
 {
-    if constexpr (LDS && kLN == 16) {
+    if constexpr (LDS && NODE == 16) {
         return *(lds_f4 *)(uintptr_t)(unsigned)a;
     } else if constexpr (LDS) {
         typedef const __attribute__((address_space(3))) float lds_f;
@@ -239,7 +253,7 @@ __device__ __forceinline__ PxC px_finish(const LutConsts &L, const Win &W, const
         const float x = fmaxf(fmaxf(dr, dg), db), y = tmed3(dr, dg, db), z = fminf(fminf(dr, dg), db);
         const bool rg = dr > dg, gb = dg > db, rb = dr > db;
         // by-value copies: a ?: over struct members is an lvalue select, which pins W in scratch
-        const int o_r = W.o_r, o_g = W.o_g, o_b = node_b<LDS>();
+        const int o_r = W.o_r, o_g = W.o_g, o_b = node_b<LDS, INTERP>();
         const int o111 = o_r + o_g + o_b;
         const int z_r = o111 - o_r, z_g = o111 - o_g, z_b = o111 - o_b;
         // first step along the axis of the largest fraction, last step along the smallest
@@ -274,16 +288,16 @@ __device__ __forceinline__ Rgb3 px_blend(const LutConsts &L, const Win &W, const
     Rgb3 v;
     const int a = c.a;
     if constexpr (INTERP == LUTR_INTERP_NEAREST) {
-        const f4 t = tap<LDS>(L.lat, a);
+        const f4 t = tap<LDS, lds_node<INTERP>()>(L.lat, a);
         v.r = t.x; v.g = t.y; v.b = t.z;
     } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
         const float dr = c.w0, dg = c.w1, db = c.w2;
         const int ag = a + W.o_g, ar = a + W.o_r, arg = ar + W.o_g;       // 3 address adds; +blue is an immediate
-        constexpr int ob = node_b<LDS>();
-        const f4 c000 = tap<LDS>(L.lat, a), c001 = tap<LDS>(L.lat, a + ob);
-        const f4 c010 = tap<LDS>(L.lat, ag), c011 = tap<LDS>(L.lat, ag + ob);
-        const f4 c100 = tap<LDS>(L.lat, ar), c101 = tap<LDS>(L.lat, ar + ob);
-        const f4 c110 = tap<LDS>(L.lat, arg), c111 = tap<LDS>(L.lat, arg + ob);
+        constexpr int ob = node_b<LDS, INTERP>();
+        const f4 c000 = tap<LDS, lds_node<INTERP>()>(L.lat, a), c001 = tap<LDS, lds_node<INTERP>()>(L.lat, a + ob);
+        const f4 c010 = tap<LDS, lds_node<INTERP>()>(L.lat, ag), c011 = tap<LDS, lds_node<INTERP>()>(L.lat, ag + ob);
+        const f4 c100 = tap<LDS, lds_node<INTERP>()>(L.lat, ar), c101 = tap<LDS, lds_node<INTERP>()>(L.lat, ar + ob);
+        const f4 c110 = tap<LDS, lds_node<INTERP>()>(L.lat, arg), c111 = tap<LDS, lds_node<INTERP>()>(L.lat, arg + ob);
 #define TRI(ch, out) \
         { \
             const float c00 = tlerp(c000.ch, c100.ch, dr), c10 = tlerp(c010.ch, c110.ch, dr); \
@@ -294,9 +308,9 @@ __device__ __forceinline__ Rgb3 px_blend(const LutConsts &L, const Win &W, const
         TRI(x, v.r) TRI(y, v.g) TRI(z, v.b)
 #undef TRI
     } else {
-        const int o111 = W.o_r + W.o_g + node_b<LDS>();
-        const f4 c0 = tap<LDS>(L.lat, a), c1 = tap<LDS>(L.lat, a + c.oa);
-        const f4 c2 = tap<LDS>(L.lat, a + c.oz), c3 = tap<LDS>(L.lat, a + o111);
+        const int o111 = W.o_r + W.o_g + node_b<LDS, INTERP>();
+        const f4 c0 = tap<LDS, lds_node<INTERP>()>(L.lat, a), c1 = tap<LDS, lds_node<INTERP>()>(L.lat, a + c.oa);
+        const f4 c2 = tap<LDS, lds_node<INTERP>()>(L.lat, a + c.oz), c3 = tap<LDS, lds_node<INTERP>()>(L.lat, a + o111);
         v.r = c.w0 * c0.x + c.w1 * c1.x + c.w2 * c2.x + c.w3 * c3.x;
         v.g = c.w0 * c0.y + c.w1 * c1.y + c.w2 * c2.y + c.w3 * c3.y;
         v.b = c.w0 * c0.z + c.w1 * c1.z + c.w2 * c2.z + c.w3 * c3.z;
@@ -359,6 +373,7 @@ __device__ __forceinline__ bool win_holds(const Win &W, const Bnd &b)
 // misses), stage it into this wave's LDS slice and describe it in W.  The r axis takes the
 // rest of the capacity, centred.  Returns false (W untouched) when the tile's colours are too
 // spread out for the slice.
+template <int kLN>
 __device__ __forceinline__ bool win_restage(Win &W, const LutConsts &L, const Bnd &bn_, int cap, int slice_off,
                                             int lds_bytes, int lane)
 {
@@ -506,6 +521,9 @@ struct TileGeom {
 // A unit is what one lane handles per tile: PXT luma samples wide, BH rows tall.  With
 // LUTR_UNIT_HALF the unit is 8 bytes of luma per row instead of 16: half the input / output /
 // prefetch registers per lane (more waves per SIMD) at twice the per-tile overhead per pixel.
+#ifndef LUTR_PIN_MORE
+#define LUTR_PIN_MORE 1
+#endif
 #ifndef LUTR_PIN_CONSTS
 #define LUTR_PIN_CONSTS 1
 #endif
@@ -696,13 +714,16 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
     if constexpr (LUTR_PIN_CONSTS && INTERP != LUTR_INTERP_TRILINEAR) {
         L.maxf = in_vgpr(L_.maxf);
         K.cyr = in_vgpr(K_.cyr); K.cyg = in_vgpr(K_.cyg); K.cyb = in_vgpr(K_.cyb);
+#if LUTR_PIN_MORE
+        K.ky = in_vgpr(K_.ky); K.yb = in_vgpr(K_.yb); K.yob = in_vgpr(K_.yob);
+#endif
     }
     if constexpr (TAB) coord_table_fill<INTERP>(L, TG.tab_bytes / 8);     // the kernel's only barrier
     using T = YuvTile<WIDE, CSX, CSY>;
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int wave = blockIdx.x * LUTR_WPB + wib;
-    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * kLN;
+    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * lds_node<INTERP>();
     int fr, sx, ry, rem;                                      // the tile being fetched next
     int round = 0;
     if (!claim_chunk(TG, lane, fr, sx, ry, rem, round)) return;   // wave-uniform; the first chunks go by wave id
@@ -710,7 +731,7 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
 
-    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * kLN;
+    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * lds_node<INTERP>();
     Win W, WG;
     win_empty(W, slice_off);
     win_global(WG, L);
@@ -756,7 +777,7 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
             bnd_reset(bn);
             yuv_tile_bounds<WIDE, CSX, CSY, INTERP, PRE, TAB>(L, K, in, bn);
             if (!lds_mode || !win_holds(W, bn)) {
-                lds_mode = win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane);
+                lds_mode = win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane);
                 if (lds_mode) ws.n[3]++;
             }
             load_tile(in, cfr, csx, cry);              // the bounds pass consumed the tile; L2 still has it
@@ -769,7 +790,7 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
                 if (win_holds(W, bn)) break;
                 // miss: re-stage around this tile's colours and redo it, or give the tile to the gather body
                 ws.n[1]++;
-                if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
+                if (!win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
                 else ws.n[3]++;
                 load_tile(in, cfr, csx, cry);          // the failed pass consumed the tile; L2 still has it
                 __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0) HERE, or the loop header waits on every pass
@@ -777,7 +798,7 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
                 yuv_tile_body<false, WIDE, CSX, CSY, INTERP, PRE, TAB>(L, K, WG, in, out, bn);
                 ws.n[2]++;
                 // colours narrow enough again?  then the next tile starts from a staged window
-                if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
+                if (win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
                 break;
             }
         }
@@ -894,14 +915,14 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
     using T = RgbTile<WIDE>;
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
-    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * kLN;
+    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * lds_node<INTERP>();
     int fr, sx, ry, rem;                                      // the tile being fetched next
     int round = 0;
     if (!claim_chunk(TG, lane, fr, sx, ry, rem, round)) return;   // wave-uniform; the first chunks go by wave id
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
 
-    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * kLN;
+    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * lds_node<INTERP>();
     Win W, WG;
     win_empty(W, slice_off);
     win_global(WG, L);
@@ -935,7 +956,7 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
             bnd_reset(bn);
             rgb_tile_bounds<WIDE, INTERP, TAB>(L, in, bn);
             if (!lds_mode || !win_holds(W, bn)) {
-                lds_mode = win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane);
+                lds_mode = win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane);
                 if (lds_mode) ws.n[3]++;
             }
             load_tile(in, cfr, csx, cry);
@@ -947,14 +968,14 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
                 rgb_tile_body<true, WIDE, INTERP, TAB>(L, W, in, out, bn);
                 if (win_holds(W, bn)) break;
                 ws.n[1]++;
-                if (!win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
+                if (!win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
                 else ws.n[3]++;
                 load_tile(in, cfr, csx, cry);
                 __builtin_amdgcn_s_waitcnt(0x0f70);
             } else {
                 rgb_tile_body<false, WIDE, INTERP, TAB>(L, WG, in, out, bn);
                 ws.n[2]++;
-                if (win_restage(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
+                if (win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
                 break;
             }
         }
@@ -1043,7 +1064,7 @@ static void read_env_tuning()
 
 // The per-code coordinate table needs equal per-channel scales (one table serves R, G and B) and a
 // depth of at most 10 bits (8 KB); the window shrinks so that 4 blocks still share the CU's 160 KB.
-static int plan_table(TileGeom *tg, const LutConsts &L)
+static int plan_table(TileGeom *tg, const LutConsts &L, int kLN)
 {
     const int entries = (int)L.maxf + 1;
     const bool ok = L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2] && entries <= 1024 && !getenv("LUTR_NO_TAB");
@@ -1080,8 +1101,8 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
     // the queue starts behind the chunks the waves take by their id (claim_chunk)
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_WPB * LUTR_STATIC_ROUNDS), 1, st) != hipSuccess) return nullptr;
-    const bool tab = plan_table(&tg, L) != 0;
-    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * kLN;
+    const bool tab = plan_table(&tg, L, lds_node_rt(mode)) != 0;
+    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * lds_node_rt(mode);
 #define RGB_CASE(W, I) \
     if (wide == W && mode == I) { \
         if (tab && L.unit) LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 2>), L, P, G, tg); \
@@ -1119,8 +1140,8 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
     // the queue starts behind the chunks the waves take by their id (claim_chunk)
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_WPB * LUTR_STATIC_ROUNDS), 1, st) != hipSuccess) return nullptr;
-    const bool tab = plan_table(&tg, L) != 0;
-    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * kLN;
+    const bool tab = plan_table(&tg, L, lds_node_rt(mode)) != 0;
+    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * lds_node_rt(mode);
     const bool pre = K.pre != 0.0f;
     // ",unit" kernels drop both output clips: lattice in [0,1] (quantisation) and YUV maxima below max_o + 1
     const bool unit = L.unit && out_clip_dead(K, 1 << (csx + csy));
