@@ -517,6 +517,26 @@ struct TileGeom {
     unsigned *stats;      // optional device counters; nullptr = off
 };
 
+// The tile kernels' view of the planes: 32-bit row strides (launch_rgb / launch_yuv only send layouts with positive
+// strides below 2^30 here), which halves the scalar registers they occupy -- the kernels run out of SGPRs and
+// every spilled one costs a v_readlane per tile.
+struct TilePlanes {
+    const uint8_t *s[3];
+    uint8_t       *d[3];
+    int ss[3], ds[3];
+    long long sfs[3], dfs[3];
+};
+static inline TilePlanes tile_planes(const PlaneSet &P)
+{
+    TilePlanes T;
+    for (int i = 0; i < 3; i++) {
+        T.s[i] = P.s[i]; T.d[i] = P.d[i];
+        T.ss[i] = (int)P.ss[i]; T.ds[i] = (int)P.ds[i];
+        T.sfs[i] = P.sfs[i]; T.dfs[i] = P.dfs[i];
+    }
+    return T;
+}
+
 // ================================================================= fused YUV tile kernel
 // A unit is what one lane handles per tile: PXT luma samples wide, BH rows tall.  With
 // LUTR_UNIT_HALF the unit is 8 bytes of luma per row instead of 16: half the input / output /
@@ -706,7 +726,7 @@ __device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &f
 
 template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
 __global__ __launch_bounds__(64 * LUTR_WPB, LUTR_TILE_WAVES_PER_EU)
-void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG)
+void k_yuv_tile(LutConsts L_, YuvConsts K_, TilePlanes P, FrameGeom G, TileGeom TG)
 {
     LutConsts L = L_;
     YuvConsts K = K_;
@@ -716,6 +736,9 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
         K.cyr = in_vgpr(K_.cyr); K.cyg = in_vgpr(K_.cyg); K.cyb = in_vgpr(K_.cyb);
 #if LUTR_PIN_MORE
         K.ky = in_vgpr(K_.ky); K.yb = in_vgpr(K_.yb); K.yob = in_vgpr(K_.yob);
+#endif
+#if LUTR_PIN_MORE > 1
+        K.krv = in_vgpr(K_.krv); K.kbu = in_vgpr(K_.kbu); K.kgu = in_vgpr(K_.kgu); K.kgv = in_vgpr(K_.kgv);
 #endif
     }
     if constexpr (TAB) coord_table_fill<INTERP>(L, TG.tab_bytes / 8);     // the kernel's only barrier
@@ -742,9 +765,9 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
     auto load_tile = [&](T &dst, int f, int tsx, int try_) {
         const int lxc = min(lx, TG.uw - 1 - tsx * lw), lyc = min(ly, TG.urows - 1 - (try_ << lh_log2));
         const long long urow0 = cr0 + (try_ << lh_log2);                  // wave-uniform
-        const uint8_t *sy = P.s[0] + f * P.sfs[0] + urow0 * T::BH * P.ss[0] + (long long)tsx * lw * YWB;
-        const uint8_t *scb = P.s[1] + f * P.sfs[1] + urow0 * P.ss[1] + (long long)tsx * lw * CWB;
-        const uint8_t *scr = P.s[2] + f * P.sfs[2] + urow0 * P.ss[2] + (long long)tsx * lw * CWB;
+        const uint8_t *sy = P.s[0] + f * P.sfs[0] + urow0 * T::BH * (long long)P.ss[0] + (long long)tsx * lw * YWB;
+        const uint8_t *scb = P.s[1] + f * P.sfs[1] + urow0 * (long long)P.ss[1] + (long long)tsx * lw * CWB;
+        const uint8_t *scr = P.s[2] + f * P.sfs[2] + urow0 * (long long)P.ss[2] + (long long)tsx * lw * CWB;
 #pragma unroll
         for (int dy = 0; dy < T::BH; dy++)
             ldw<T::YW>(dst.y[dy], sy + (unsigned)((lyc * T::BH + dy) * (int)P.ss[0] + lxc * YWB));
@@ -807,9 +830,9 @@ void k_yuv_tile(LutConsts L_, YuvConsts K_, PlaneSet P, FrameGeom G, TileGeom TG
             // so they store the same bytes to the same place as its owner: no branch, fixed store count.
             const int lxc = min(lx, TG.uw - 1 - csx * lw), lyc = min(ly, TG.urows - 1 - (cry << lh_log2));
             const long long urow0 = cr0 + (cry << lh_log2);
-            uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * P.ds[0] + (long long)csx * lw * YWB;
-            uint8_t *dcb = P.d[1] + cfr * P.dfs[1] + urow0 * P.ds[1] + (long long)csx * lw * CWB;
-            uint8_t *dcr = P.d[2] + cfr * P.dfs[2] + urow0 * P.ds[2] + (long long)csx * lw * CWB;
+            uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * (long long)P.ds[0] + (long long)csx * lw * YWB;
+            uint8_t *dcb = P.d[1] + cfr * P.dfs[1] + urow0 * (long long)P.ds[1] + (long long)csx * lw * CWB;
+            uint8_t *dcr = P.d[2] + cfr * P.dfs[2] + urow0 * (long long)P.ds[2] + (long long)csx * lw * CWB;
 #pragma unroll
             for (int dy = 0; dy < T::BH; dy++)
                 stw<T::YW>(dy_ + (unsigned)((lyc * T::BH + dy) * (int)P.ds[0] + lxc * YWB), out.y[dy]);
@@ -907,7 +930,7 @@ __device__ __forceinline__ void rgb_tile_bounds(const LutConsts &L, RgbTile<WIDE
 
 template <int WIDE, int INTERP, int TAB>
 __global__ __launch_bounds__(64 * LUTR_WPB, LUTR_TILE_WAVES_PER_EU)
-void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
+void k_rgb_tile(LutConsts L_, TilePlanes P, FrameGeom G, TileGeom TG)
 {
     LutConsts L = L_;
     if constexpr (LUTR_PIN_CONSTS && INTERP != LUTR_INTERP_TRILINEAR) L.maxf = in_vgpr(L_.maxf);
@@ -932,9 +955,9 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
         const int lxc = min(lx, TG.uw - 1 - tsx * lw), lyc = min(ly, TG.urows - 1 - (try_ << lh_log2));
         const long long row0 = G.row0 + (try_ << lh_log2);                // wave-uniform
         const long long xb = (long long)tsx * lw * 16;
-        ldw<4>(dst.g, P.s[0] + f * P.sfs[0] + row0 * P.ss[0] + xb + (unsigned)(lyc * (int)P.ss[0] + lxc * 16));
-        ldw<4>(dst.b, P.s[1] + f * P.sfs[1] + row0 * P.ss[1] + xb + (unsigned)(lyc * (int)P.ss[1] + lxc * 16));
-        ldw<4>(dst.r, P.s[2] + f * P.sfs[2] + row0 * P.ss[2] + xb + (unsigned)(lyc * (int)P.ss[2] + lxc * 16));
+        ldw<4>(dst.g, P.s[0] + f * P.sfs[0] + row0 * (long long)P.ss[0] + xb + (unsigned)(lyc * (int)P.ss[0] + lxc * 16));
+        ldw<4>(dst.b, P.s[1] + f * P.sfs[1] + row0 * (long long)P.ss[1] + xb + (unsigned)(lyc * (int)P.ss[1] + lxc * 16));
+        ldw<4>(dst.r, P.s[2] + f * P.sfs[2] + row0 * (long long)P.ss[2] + xb + (unsigned)(lyc * (int)P.ss[2] + lxc * 16));
     };
 
     WaveStats ws;
@@ -983,9 +1006,9 @@ void k_rgb_tile(LutConsts L_, PlaneSet P, FrameGeom G, TileGeom TG)
             const int lxc = min(lx, TG.uw - 1 - csx * lw), lyc = min(ly, TG.urows - 1 - (cry << lh_log2));
             const long long row0 = G.row0 + (cry << lh_log2);
             const long long xb = (long long)csx * lw * 16;
-            stw<4>(P.d[0] + cfr * P.dfs[0] + row0 * P.ds[0] + xb + (unsigned)(lyc * (int)P.ds[0] + lxc * 16), out.g);
-            stw<4>(P.d[1] + cfr * P.dfs[1] + row0 * P.ds[1] + xb + (unsigned)(lyc * (int)P.ds[1] + lxc * 16), out.b);
-            stw<4>(P.d[2] + cfr * P.dfs[2] + row0 * P.ds[2] + xb + (unsigned)(lyc * (int)P.ds[2] + lxc * 16), out.r);
+            stw<4>(P.d[0] + cfr * P.dfs[0] + row0 * (long long)P.ds[0] + xb + (unsigned)(lyc * (int)P.ds[0] + lxc * 16), out.g);
+            stw<4>(P.d[1] + cfr * P.dfs[1] + row0 * (long long)P.ds[1] + xb + (unsigned)(lyc * (int)P.ds[1] + lxc * 16), out.b);
+            stw<4>(P.d[2] + cfr * P.dfs[2] + row0 * (long long)P.ds[2] + xb + (unsigned)(lyc * (int)P.ds[2] + lxc * 16), out.r);
         }
         ws.n[0]++;
     }
@@ -1102,12 +1125,13 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     // the queue starts behind the chunks the waves take by their id (claim_chunk)
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_WPB * LUTR_STATIC_ROUNDS), 1, st) != hipSuccess) return nullptr;
     const bool tab = plan_table(&tg, L, lds_node_rt(mode)) != 0;
+    const TilePlanes TP = tile_planes(P);
     const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * lds_node_rt(mode);
 #define RGB_CASE(W, I) \
     if (wide == W && mode == I) { \
-        if (tab && L.unit) LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 2>), L, P, G, tg); \
-        else if (tab) LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 1>), L, P, G, tg); \
-        else LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 0>), L, P, G, tg); \
+        if (tab && L.unit) LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 2>), L, TP, G, tg); \
+        else if (tab) LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 1>), L, TP, G, tg); \
+        else LUTR_LAUNCH_TILE((k_rgb_tile<W, I, 0>), L, TP, G, tg); \
         return tab ? (L.unit ? "k_rgb_tile<" #W "," #I ",tab,unit>" : "k_rgb_tile<" #W "," #I ",tab>") : "k_rgb_tile<" #W "," #I ">"; \
     }
     RGB_CASE(0, 0) RGB_CASE(0, 1) RGB_CASE(0, 2)
@@ -1141,6 +1165,7 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     // the queue starts behind the chunks the waves take by their id (claim_chunk)
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_WPB * LUTR_STATIC_ROUNDS), 1, st) != hipSuccess) return nullptr;
     const bool tab = plan_table(&tg, L, lds_node_rt(mode)) != 0;
+    const TilePlanes TP = tile_planes(P);
     const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * lds_node_rt(mode);
     const bool pre = K.pre != 0.0f;
     // ",unit" kernels drop both output clips: lattice in [0,1] (quantisation) and YUV maxima below max_o + 1
@@ -1153,11 +1178,11 @@ const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts 
     }
 #define YUV_CASE(W, X, Y, I) \
     if (win == W && csx == X && csy == Y && mode == I) { \
-        if (pre && tab) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, true, 1>), L, K, P, G, tg); \
-        else if (pre) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, true, 0>), L, K, P, G, tg); \
-        else if (tab && unit) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 2>), L, K, P, G, tg); \
-        else if (tab) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 1>), L, K, P, G, tg); \
-        else LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 0>), L, K, P, G, tg); \
+        if (pre && tab) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, true, 1>), L, K, TP, G, tg); \
+        else if (pre) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, true, 0>), L, K, TP, G, tg); \
+        else if (tab && unit) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 2>), L, K, TP, G, tg); \
+        else if (tab) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 1>), L, K, TP, G, tg); \
+        else LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 0>), L, K, TP, G, tg); \
         return pre ? (tab ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre,tab>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre>") \
                    : (tab ? (unit ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab,unit>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab>") \
                           : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"); \
