@@ -22,6 +22,12 @@
 //     Waves walk DOWN a column strip, so consecutive tiles mostly hit.
 //   * No workgroup barrier in the tile loop (one at kernel start, after the coordinate table is
 //     filled): waves are independent; a wave's only shared state is its own LDS slice.
+//   * Persistent grid (16 waves per CU in 8-wave workgroups that share one per-code coordinate
+//     table); work is handed out in chunks of 16 tile rows through one atomic counter, every
+//     wave's first chunk by its id (no burst of atomics at start-up).
+//   * LDS nodes are 12 bytes {r,g,b} for the 4-tap modes, 16 for trilinear (DESIGN.md "Kernels").
+//   * Launches too small to fill this machinery go to the plain vector kernels instead
+//     (lutr_kernels.hip small_job()).
 //
 // Arithmetic is the strict restatement (see lutr_kernels.hip): -ffp-contract=off, FFmpeg's
 // scalar C order, bit-identical to the oracle.
@@ -538,24 +544,19 @@ static inline TilePlanes tile_planes(const PlaneSet &P)
 }
 
 // ================================================================= fused YUV tile kernel
-// A unit is what one lane handles per tile: PXT luma samples wide, BH rows tall.  With
-// LUTR_UNIT_HALF the unit is 8 bytes of luma per row instead of 16: half the input / output /
-// prefetch registers per lane (more waves per SIMD) at twice the per-tile overhead per pixel.
+// A unit is what one lane handles per tile: 16 bytes of luma per row (PXT samples), BH rows tall.
 #ifndef LUTR_PIN_MORE
 #define LUTR_PIN_MORE 1
 #endif
 #ifndef LUTR_PIN_CONSTS
 #define LUTR_PIN_CONSTS 1
 #endif
-#ifndef LUTR_UNIT_HALF
-#define LUTR_UNIT_HALF 0
-#endif
 template <int WIDE, int CSX, int CSY>
 struct YuvTile {
-    static constexpr int PXT = (WIDE ? 8 : 16) >> LUTR_UNIT_HALF;
+    static constexpr int PXT = WIDE ? 8 : 16;
     static constexpr int BH = 1 << CSY, BW = 1 << CSX;
     static constexpr int NC = PXT >> CSX;
-    static constexpr int YW = 4 >> LUTR_UNIT_HALF;                 // 32-bit words of luma per row
+    static constexpr int YW = 4;                                   // 32-bit words of luma per row
     static constexpr int CW = NC * (WIDE ? 2 : 1) / 4;             // 32-bit words of each chroma plane
     uint32_t y[BH][YW], cb[CW], cr[CW];
 };
@@ -1157,7 +1158,7 @@ static bool out_clip_dead(const YuvConsts &K, int chroma_n)
 const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
                             const FrameGeom &G, int win, int csx, int csy, int mode, unsigned *stats, unsigned *queue)
 {
-    const int pxt = (win ? 8 : 16) >> LUTR_UNIT_HALF;
+    const int pxt = win ? 8 : 16;
     TileGeom tg;
     read_env_tuning();
     plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
