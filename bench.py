@@ -56,7 +56,8 @@ def parse_args():
     ap.add_argument("--unique", type=int, default=2, help="distinct synthetic frames tiled into the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true", help="skip the extra LDS-window statistics pass (profiling runs)")
-    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="wall budget of the CPU baseline sample (all host cores: ~10 s wall on 256 threads)")
     ap.add_argument("--extra", action="store_true", help="also time the other distribution / mode (stderr only)")
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed kernel launches before the W warm-up steps until this much time has passed: the GPU "
