@@ -2,25 +2,35 @@
 """bench.py -- Mpixels/s of the 3D-LUT apply hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the fused kernel over a batch of synthetic frames that is already
-resident in HBM.  Default workload = BASELINE.json configs[1]: 3840x2160 yuv420p10le,
-33^3 log->Rec.709 .cube, tetrahedral, 1 GPU, 256 frames per launch (12.7 GB of the 288 GB HBM).  With N > 1 every frame is split into N row
-blocks; rank g owns block g of N x FRAMES frames, so per-GPU work is fixed
-("weak" scaling); the only collective is the RCCL broadcast of the lattice at LUT load.
+With N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks (one per GPU,
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a child
+process, before this process has touched the GPU) and relays rank 0's JSON line; launched by
+torch.distributed.run itself it is one of the ranks.
 
-Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (6 B/px
-for yuv420p10le in+out, + the 431,244 B lattice) / the kernel's mean launch duration
-measured with HIP events on the launch stream.  `cpu_baseline` times the CPU oracle
-(kind "port": a restatement of FFmpeg lut3d, not FFmpeg) on the host cores.
+A "step" is one pass of the fused kernel over a batch of synthetic frames that is already resident in
+HBM.  Default workload = BASELINE.json configs[1]: 3840x2160 yuv420p10le, 33^3 log->Rec.709 .cube,
+tetrahedral, 256 frames per GPU and step (12.7 GB of the 288 GB HBM).
+
+Multi-GPU: every frame is split into N row blocks with FFmpeg's slice rule; rank g owns
+block g and launches on the SHARED full-height planes with row0 = its first row.  `value` is weak
+scaling (N x FRAMES frames, so per-GPU work is fixed); `strong` in the same line is the row-shard
+speed-up north_star words: the same FRAMES frames, rows split N ways.  The only collective is the RCCL
+broadcast of the lattice at LUT load, reported in `collective`.
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (6 B/px for
+yuv420p10le in+out, + the 431,244 B lattice) / the kernel's mean launch duration measured with HIP
+events on the launch stream.  `cpu_baseline` times the CPU oracle (kind "port": a restatement of FFmpeg
+lut3d, not FFmpeg) on the host cores.  `extra_Mpx_s` carries the same kernel on other frame statistics
+(sensor noise swept up to sigma = 64 codes, i.i.d. uniform) with the LDS-window hit / miss / gather counts.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -29,18 +39,16 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 SIZES = {"1080p": (1920, 1080), "uhd": (3840, 2160), "8k": (7680, 4320)}
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+EXTRA_DISTS = ("noise8", "noise16", "noise64", "uniform")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -49,16 +57,26 @@ def parse_args():
                     help="frames per GPU per step (SURVEY 8d: >= 64; 256 = the batch of BASELINE config 5: 6.4 GB in + 6.4 GB out)")
     ap.add_argument("--size", default="uhd", choices=sorted(SIZES))
     ap.add_argument("--fmt", default="yuv420p10le")
+    ap.add_argument("--out-fmt", default=None, help="output pixel format (default: same as --fmt); e.g. yuv420p for the "
+                                                    "reference's libx264 default on a 10-bit source (ffmpeg.py:287-302)")
+    ap.add_argument("--range-src", default="tv", choices=["tv", "pc"],
+                    help="pc: full-range source -> the reference's prologue scale=in_range=pc:out_range=tv,format=<8-bit> "
+                         "(ffmpeg.py:212-233, BASELINE config 5) runs fused ahead of the LUT")
     ap.add_argument("--interp", default="tetrahedral")
+    ap.add_argument("--precision", default="strict", choices=["strict", "fast"],
+                    help="strict: bit-exact restatement of FFmpeg's scalar C; fast: tolerance-bounded variant "
+                         "(<= 1 code from strict at 8 and 10 bit, tests/test_gpu_parity.py)")
     ap.add_argument("--lut", type=int, default=33, help="lattice size N of the generated log709 LUT")
-    ap.add_argument("--dist", default="natural", choices=["natural", "uniform"])
+    ap.add_argument("--dist", default="natural")
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--unique", type=int, default=2, help="distinct synthetic frames tiled into the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true", help="skip the extra LDS-window statistics pass (profiling runs)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other-content lines (extra_Mpx_s)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling pass (N > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="wall budget of the CPU baseline sample (all host cores: ~10 s wall on 256 threads)")
-    ap.add_argument("--extra", action="store_true", help="also time the other distribution / mode (stderr only)")
+    ap.add_argument("--extra-modes", action="store_true", help="extra_Mpx_s also for trilinear")
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed kernel launches before the W warm-up steps until this much time has passed: the GPU "
                          "needs ~20 ms of load to leave its idle clock (DESIGN.md 5), whatever W the caller picks")
@@ -68,10 +86,27 @@ def parse_args():
                     help="host: also time BASELINE config 5 (frames in pinned host memory, overlapped copies); "
                          "reported as `host_pipeline`, never as `value`")
     ap.add_argument("--host-frames", type=int, default=256)
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------- self-launch (N > 1 without a launcher)
+def spawn_ranks(n: int) -> int:
+    """Start N fresh ranks as a child process tree and relay their output.  This process has not initialised the
+    GPU (no torch.cuda call so far) and never replaces itself: it waits for the child and returns its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    log(f"[bench] starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
 
 
 def dist_setup(gpus: int):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -88,9 +123,7 @@ def dist_setup(gpus: int):
         else:
             dist.init_process_group(backend=backend)
         assert dist.get_world_size() == gpus, f"--gpus {gpus} but WORLD_SIZE {world}"
-    elif gpus != 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
-    return rank, local, world
+    return rank, local, world, backend
 
 
 def barrier(world):
@@ -99,60 +132,89 @@ def barrier(world):
         dist.barrier()
 
 
-DITHER = "none"
+class Job:
+    """What one timed launch does: format pair, mode, prologue, row range."""
+
+    def __init__(self, args, pf, pf_out):
+        self.args, self.pf, self.pf_out = args, pf, pf_out
+        self.kw = {}
+        if pf.family == "yuv":
+            self.kw = dict(pix_fmt=args.fmt, out_pix_fmt=args.out_fmt or args.fmt)
+            if args.range_src == "pc":
+                # ffmpeg.py:212-233: scale=in_range=pc:out_range=tv , format=<8-bit intermediate>: the LUT runs at 8 bit
+                self.kw.update(range_src="pc", range_in="tv", lut_depth=8)
+            if args.dither != "none":
+                self.kw["dither"] = args.dither
+
+    def apply(self, eng, src, dst, interp, row0=0, rows=None):
+        pf = self.pf
+        if pf.family == "packed":
+            return eng.apply_packed(src[0], dst[0], pix_fmt=self.args.fmt, interp=interp, row0=row0, rows=rows)
+        if pf.family == "gbr":
+            return eng.apply_rgb(src, dst, depth=pf.depth, interp=interp, row0=row0, rows=rows)
+        if self.args.dither != "none":
+            return eng.apply_yuv(src, dst, interp=interp, **self.kw)
+        return eng.apply_yuv(src, dst, interp=interp, row0=row0, rows=rows, **self.kw)
 
 
-def apply(eng, pf, src, dst, fmt, interp):
-    if DITHER != "none":
-        return eng.apply_yuv(src, dst, pix_fmt=fmt, interp=interp, dither=DITHER)
-    if pf.family == "packed":
-        return eng.apply_packed(src[0], dst[0], pix_fmt=fmt, interp=interp)
-    if pf.family == "gbr":
-        return eng.apply_rgb(src, dst, depth=pf.depth, interp=interp)
-    return eng.apply_yuv(src, dst, pix_fmt=fmt, interp=interp)
-
-
-def build_batch(eng, pf, w, h, r0, r1, nframes, dist_name, unique):
-    """Rows [r0,r1) of `unique` synthetic frames, tiled to `nframes` frames on the device."""
+def make_frames(pf, w, h, dist_name, k, full_range):
     from lut_renderer_amd import frames
+    if pf.family in ("gbr", "packed"):
+        return frames.make_rgb(dist_name, w, h, pf.depth, k=k)
+    return frames.make_yuv(dist_name, w, h, pf.depth, pf.csx, pf.csy, k=k, full_range=full_range)
+
+
+def build_batch(eng, pf, w, h, nframes, dist_name, unique, full_range=False):
+    """`unique` synthetic full-height frames tiled to `nframes` frames on the device."""
+    import numpy as np
+    import torch
+    reps = (nframes + unique - 1) // unique
     if pf.family == "packed":                            # interleave the planar RGB generator's frames
         imgs = []
         for k in range(unique):
-            g, b, r = (frames.natural_rgb if dist_name == "natural" else frames.uniform_rgb)(w, h, pf.depth, k=k)
-            img = np.full((r1 - r0, w, pf.nc), (1 << pf.depth) - 1, dtype=g.dtype)
-            img[..., pf.rgb[0]], img[..., pf.rgb[1]], img[..., pf.rgb[2]] = r[r0:r1], g[r0:r1], b[r0:r1]
+            g, b, r = make_frames(pf, w, h, dist_name, k, full_range)
+            img = np.full((h, w, pf.nc), (1 << pf.depth) - 1, dtype=g.dtype)
+            img[..., pf.rgb[0]], img[..., pf.rgb[1]], img[..., pf.rgb[2]] = r, g, b
             imgs.append(torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img))
         u = torch.stack(imgs).to(eng.device)
-        return [u.repeat((nframes + unique - 1) // unique, 1, 1, 1)[:nframes].contiguous()]
-    bh = 1 << pf.csy
+        return [u.repeat(reps, 1, 1, 1)[:nframes].contiguous()]
     planes = [[], [], []]
     for k in range(unique):
-        if pf.family == "gbr":
-            f = (frames.natural_rgb if dist_name == "natural" else frames.uniform_rgb)(w, h, pf.depth, k=k)
-        else:
-            f = frames.make_yuv(dist_name, w, h, pf.depth, pf.csx, pf.csy, k=k)
-        sl = [f[0][r0:r1], f[1][r0 // bh:(r1 + bh - 1) // bh], f[2][r0 // bh:(r1 + bh - 1) // bh]]
+        f = make_frames(pf, w, h, dist_name, k, full_range)
         for i in range(3):
-            a = np.ascontiguousarray(sl[i])
+            a = np.ascontiguousarray(f[i])
             planes[i].append(torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a))
     out = []
     for i in range(3):
         u = torch.stack(planes[i]).to(eng.device)
-        reps = (nframes + unique - 1) // unique
         out.append(u.repeat(reps, 1, 1)[:nframes].contiguous())
     return out
+
+
+def alloc_out(eng, job, src, w, h):
+    import torch
+    pf, pfo = job.pf, job.pf_out
+    if pf.family != "yuv" or pfo is pf:
+        return [torch.empty_like(t) for t in src]
+    dt = torch.uint8 if pfo.depth <= 8 else torch.int16
+    nf = src[0].shape[0]
+    return [torch.empty((nf,) + pfo.plane_shape(i, w, h), dtype=dt, device=eng.device) for i in range(3)]
 
 
 PREWARM_MS = 0.0
 
 
-def time_steps(eng, pf, src, dst, fmt, interp, steps, warmup, world):
+def time_steps(eng, job, src, dst, interp, steps, warmup, world, row0=0, rows=None, nframes=None):
+    """Returns (wall seconds for `steps` launches, mean kernel seconds from HIP events on the launch stream)."""
+    import torch
+    if nframes is not None:
+        src, dst = [t[:nframes] for t in src], [t[:nframes] for t in dst]
     t_end = time.perf_counter() + PREWARM_MS / 1e3
     while time.perf_counter() < t_end:                 # clock ramp; not part of W, not timed
-        apply(eng, pf, src, dst, fmt, interp)
+        job.apply(eng, src, dst, interp, row0, rows)
         torch.cuda.synchronize()
     for _ in range(warmup):
-        apply(eng, pf, src, dst, fmt, interp)
+        job.apply(eng, src, dst, interp, row0, rows)
     torch.cuda.synchronize()
     barrier(world)
     torch.cuda.synchronize()
@@ -160,33 +222,44 @@ def time_steps(eng, pf, src, dst, fmt, interp, steps, warmup, world):
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(steps):
-        apply(eng, pf, src, dst, fmt, interp)
+        job.apply(eng, src, dst, interp, row0, rows)
     ev1.record()
     torch.cuda.synchronize()
     barrier(world)
     wall = time.perf_counter() - t0
-    return wall, ev0.elapsed_time(ev1) / 1e3 / steps     # wall seconds, mean kernel seconds (HIP events)
+    return wall, ev0.elapsed_time(ev1) / 1e3 / steps
 
 
-def cpu_baseline(lut, pf, w, h, interp, dist_name, budget_s):
+def reduce_max_sum(eng, world, maxes, sums):
+    import torch
+    if world == 1:
+        return list(maxes), list(sums)
+    import torch.distributed as dist
+    dev = eng.device if dist.get_backend() == "nccl" else "cpu"
+    tm = torch.tensor(maxes, dtype=torch.float64, device=dev)
+    ts = torch.tensor(sums, dtype=torch.float64, device=dev)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    return tm.tolist(), ts.tolist()
+
+
+def cpu_baseline(lut, job, w, h, interp, dist_name, budget_s):
     """CPU oracle (port of FFmpeg lut3d + this repo's YUV contract) on all host cores, row-sliced
     like FFmpeg's slice threads; bounded sample of the same workload."""
-    from lut_renderer_amd import frames
     from oracle import binding as orc
+    pf, pfo, args = job.pf, job.pf_out, job.args
     cores = os.cpu_count() or 1
-    # whole frames until the budget is spent (>= 2 repetitions); rows are split over `cores` threads
+    f = make_frames(pf, w, h, dist_name, 0, args.range_src == "pc")
     if pf.family == "gbr":
-        f = (frames.natural_rgb if dist_name == "natural" else frames.uniform_rgb)(w, h, pf.depth, k=0)
-
         def run():
             orc.apply_rgb(lut.table, lut.scale, pf.depth, interp, f, nthreads=cores)
     else:
-        f = frames.make_yuv(dist_name, w, h, pf.depth, pf.csx, pf.csy, k=0)
-        k = orc.yuv_constants("bt709", "tv", "bt709", "tv", pf.depth, pf.depth, pf.depth, 1 << (pf.csx + pf.csy))
+        ld = 8 if args.range_src == "pc" else pf.depth
+        k = orc.yuv_constants("bt709", "tv", "bt709", "tv", pf.depth, ld, pfo.depth, 1 << (pf.csx + pf.csy),
+                              prologue=args.range_src == "pc")
 
         def run():
-            orc.apply_yuv(lut.table, lut.scale, interp, k, pf.depth, pf.depth, pf.depth, pf.csx, pf.csy, f,
-                          nthreads=cores)
+            orc.apply_yuv(lut.table, lut.scale, interp, k, pf.depth, ld, pfo.depth, pf.csx, pf.csy, f, nthreads=cores)
     run()
     n, t0 = 0, time.perf_counter()
     while True:
@@ -211,26 +284,43 @@ def load_traffic(tag):
     return None
 
 
+def bytes_per_px(pf):
+    base = (float(pf.nc) if pf.family == "packed" else 3.0 if pf.family == "gbr"
+            else 1.0 + 2.0 / (1 << (pf.csx + pf.csy)))
+    return base * (1 if pf.depth <= 8 else 2)
+
+
 def main():
     args = parse_args()
-    global DITHER, PREWARM_MS
-    DITHER = args.dither
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))       # before anything here touches the GPU
+
+    import numpy as np  # noqa: F401
+    import torch
+    global PREWARM_MS
     PREWARM_MS = args.prewarm_ms
-    rank, local, world = dist_setup(args.gpus)
+    rank, local, world, backend = dist_setup(args.gpus)
     from lut_renderer_amd import cube
+    from lut_renderer_amd._native import PACKED_FORMATS
     from lut_renderer_amd.engine import LutEngine, parse_pix_fmt
     from lut_renderer_amd.shard import my_rows
 
     w, h = SIZES[args.size]
-    from lut_renderer_amd._native import PACKED_FORMATS
     if args.fmt in PACKED_FORMATS:
         from types import SimpleNamespace
         bits, nc, *rgb = PACKED_FORMATS[args.fmt]
-        pf = SimpleNamespace(family="packed", depth=bits, csx=0, csy=0, nc=nc, rgb=rgb)
+        pf = SimpleNamespace(family="packed", depth=bits, csx=0, csy=0, nc=nc, rgb=rgb, name=args.fmt)
+        pf_out = pf
     else:
         pf = parse_pix_fmt(args.fmt)
+        pf_out = parse_pix_fmt(args.out_fmt) if args.out_fmt and args.out_fmt != args.fmt else pf
+    job = Job(args, pf, pf_out)
     eng = LutEngine(local)
     eng.set_variant(args.variant)
+    if hasattr(eng, "set_precision"):
+        eng.set_precision(args.precision)
+    elif args.precision != "strict":
+        raise SystemExit("this build has no fast variant")
 
     # LUT: generated log->Rec.709 lattice written as a real .cube, parsed by liblutr on rank 0,
     # broadcast to the other ranks (the path's only collective)
@@ -239,58 +329,84 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             lut = cube.read_cube(cube.write_cube(Path(d) / f"log709_{args.lut}.cube", cube.log709_lattice(args.lut),
                                                  title=f"log709 {args.lut}"))
+    collective = None
     if world > 1:
-        eng.set_lut_distributed(lut, src=0)
+        eng.set_lut_distributed(lut, src=0)                 # first use also builds the communicator
+        torch.cuda.synchronize()
+        barrier(world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.set_lut_distributed(lut, src=0)                 # the steady-state cost of a LUT change
+        e1.record()
+        torch.cuda.synchronize()
+        lat_bytes = eng.lattice_tensor().numel() * 4
+        import torch.distributed as dist
+        collective = {"backend": f"{dist.get_backend()}" + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else ""),
+                      "world": dist.get_world_size(), "op": "broadcast(lattice), root 0, once per LUT load",
+                      "bcast_bytes": int(lat_bytes + 16), "bcast_us": round(e0.elapsed_time(e1) * 1e3, 1),
+                      "data_path_collectives": 0}
     else:
         eng.set_lut(lut)
 
-    r0, r1 = my_rows(h, rank, world, align=1 << pf.csy)
-    nframes = args.frames * world                     # weak scaling: block g of world x FRAMES frames
-    src = build_batch(eng, pf, w, h, r0, r1, nframes, args.dist, args.unique)
-    dst = [torch.empty_like(t) for t in src]
+    align = 1 << pf.csy
+    r0, r1 = my_rows(h, rank, world, align=align)
+    nframes = args.frames * world                     # weak scaling: row block g of world x FRAMES full-height frames
+    full_range = args.range_src == "pc"
+    src = build_batch(eng, pf, w, h, nframes, args.dist, args.unique, full_range)
+    dst = alloc_out(eng, job, src, w, h)
     px_rank = (r1 - r0) * w * nframes
 
-    wall, kern = time_steps(eng, pf, src, dst, args.fmt, args.interp, args.steps, args.warmup, world)
+    wall, kern = time_steps(eng, job, src, dst, args.interp, args.steps, args.warmup, world, r0, r1 - r0)
     kernel_name = eng.last_kernel
     tile_stats = None
     if "tile" in kernel_name and not args.no_stats:   # one extra, untimed pass with the window counters armed
         eng.tile_stats(True)
-        apply(eng, pf, src, dst, args.fmt, args.interp)
+        job.apply(eng, src, dst, args.interp, r0, r1 - r0)
         tile_stats = eng.tile_stats(False)
         if rank == 0:
             log(f"[tile stats] {tile_stats}")
-    t = torch.tensor([wall, kern, float(px_rank)], dtype=torch.float64, device=eng.device)
-    if world > 1:
-        import torch.distributed as dist
-        tm = t.clone()
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        ts = t.clone()
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        wall, kern, px_total = tm[0].item(), tm[1].item(), ts[2].item()
-    else:
-        px_total = float(px_rank)
+    (wall, kern), (px_total,) = reduce_max_sum(eng, world, [wall, kern], [float(px_rank)])
+
+    strong = None
+    if world > 1 and not args.no_strong:
+        # the same FRAMES frames as a 1-GPU run, rows split N ways
+        sw, sk = time_steps(eng, job, src, dst, args.interp, args.steps, max(2, args.warmup // 4), world, r0, r1 - r0,
+                            nframes=args.frames)
+        (sw, sk), _ = reduce_max_sum(eng, world, [sw, sk], [0.0])
+        strong = {"value": round(args.frames * w * h * args.steps / sw / 1e6, 1), "unit": "Mpixels/s",
+                  "frames": args.frames, "rows_per_gpu": r1 - r0, "ms_per_step": round(sw / args.steps * 1e3, 4),
+                  "kernel_ms": round(sk * 1e3, 4),
+                  "note": "strong scaling: the N=1 workload (same frames), every frame split into N row blocks"}
 
     extra = {}
-    if args.extra and rank == 0 and world == 1:
-        for dname in ("natural", "uniform"):
-            for mode in ("tetrahedral", "trilinear"):
-                s2 = build_batch(eng, pf, w, h, r0, r1, nframes, dname, args.unique)
-                _, k2 = time_steps(eng, pf, s2, dst, args.fmt, mode, max(3, args.steps // 2), max(2, args.warmup // 2), 1)
-                extra[f"{dname}/{mode}"] = round(px_rank / k2 / 1e6, 1)
+    if not args.no_extra and rank == 0 and world == 1 and pf.family == "yuv" and args.dither == "none":
+        modes = ("tetrahedral", "trilinear") if args.extra_modes else (args.interp,)
+        nf_x = min(nframes, 64)
+        for dname in EXTRA_DISTS:
+            if dname == args.dist:
+                continue
+            s2 = build_batch(eng, pf, w, h, nf_x, dname, args.unique, full_range)
+            d2 = [t[:nf_x] for t in dst]
+            for mode in modes:
+                _, k2 = time_steps(eng, job, s2, d2, mode, 8, 3, 1)
                 eng.tile_stats(True)
-                apply(eng, pf, s2, dst, args.fmt, mode)
-                log(f"[extra] {dname:8s} {mode:12s} {extra[f'{dname}/{mode}']:>12.1f} Mpx/s  ({eng.last_kernel}) "
-                    f"{eng.tile_stats(False)}")
-                del s2
+                job.apply(eng, s2, d2, mode)
+                st = eng.tile_stats(False)
+                key = dname if len(modes) == 1 else f"{dname}/{mode}"
+                extra[key] = {"Mpx_s": round(nf_x * w * h / k2 / 1e6, 1), "kernel": eng.last_kernel,
+                              "tiles": st["tiles"], "window_misses": st["misses"], "gather_tiles": st["global_tiles"],
+                              "windows_staged": st["staged"]}
+                log(f"[extra] {key:22s} {extra[key]}")
+            del s2
 
     host_pipe = None
     if args.pipeline == "host" and pf.family == "yuv":
         # BASELINE config 5: frames queued in pinned host memory, round-robin over the GPUs (whole frames per rank,
         # every rank drives its own 3-slot ring); total = all ranks' frames / the slowest rank's time
-        from lut_renderer_amd import frames as _frames
         from lut_renderer_amd.stream import HostPipeline
-        pipe = HostPipeline(eng, args.fmt, w, h, batch=8, slots=3, interp=args.interp)
-        full = _frames.make_yuv(args.dist, w, h, pf.depth, pf.csx, pf.csy, k=0)
+        kw = {k: v for k, v in job.kw.items() if k not in ("pix_fmt", "out_pix_fmt")}
+        pipe = HostPipeline(eng, args.fmt, w, h, batch=8, slots=3, out_pix_fmt=args.out_fmt, interp=args.interp, **kw)
+        full = make_frames(pf, w, h, args.dist, 0, full_range)
         one = b"".join(np.ascontiguousarray(p).tobytes() for p in full)
         for sl in range(pipe.slots):                 # inputs pre-filled: the producer is not what is measured
             pipe.host_in(sl)[:] = np.frombuffer(one * pipe.batch, dtype=np.uint8)
@@ -303,30 +419,30 @@ def main():
         torch.cuda.synchronize()
         barrier(world)
         el = time.perf_counter() - t0
-        tot = torch.tensor([float(n_done)], dtype=torch.float64, device=eng.device)
-        if world > 1:
-            import torch.distributed as dist
-            te = torch.tensor([el], dtype=torch.float64, device=eng.device)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            el = te.item()
-        n_all = int(tot.item())
+        (el,), (n_all,) = reduce_max_sum(eng, world, [el], [float(n_done)])
+        n_all = int(n_all)
         gb = n_all * (pipe.fin.frame_bytes + pipe.fout.frame_bytes) / 1e9
         host_pipe = {"frames": n_all, "fps": round(n_all / el, 1), "Mpixels_s": round(n_all * w * h / el / 1e6, 1),
-                     "pcie_GBps_each_way": round(gb / 2 / el, 1), "gpus": world,
+                     "pcie_GBps_each_way": round(gb / 2 / el, 1), "gpus": world, "kernel": eng.last_kernel,
+                     "prologue": "scale=in_range=pc:out_range=tv,format=<8-bit> fused" if full_range else "none",
                      "note": "frames in pinned host memory, round-robin over the GPUs, per GPU a 3-slot ring of 8-frame "
                              "batches with H2D / kernel / D2H on separate streams; PCIe Gen5 x16-bound (63 GB/s per "
                              "direction and GPU by spec); pcie_GBps_each_way is the sum over GPUs"}
         if rank == 0:
             log(f"[host pipeline] {host_pipe}")
+
     if rank == 0:
-        bpp_in = (float(pf.nc) if pf.family == "packed" else 3.0 if pf.family == "gbr"
-                  else 1.0 + 2.0 / (1 << (pf.csx + pf.csy))) * (1 if pf.depth <= 8 else 2)
-        bpp = 2.0 * bpp_in                                        # in + out, same format
+        bpp_in, bpp_out = bytes_per_px(pf), bytes_per_px(pf_out)
+        bpp = bpp_in + bpp_out
         lattice_bytes = 3 * args.lut ** 3 * 4
         bytes_launch = bpp * px_rank + lattice_bytes              # per launch on one GPU
         achieved = bytes_launch / kern / 1e9
         tag = f"{args.size}_{args.fmt}_{args.interp}_lut{args.lut}_{args.dist}_f{args.frames}"
+        if args.precision != "strict":
+            tag += f"_{args.precision}"
+        traffic = load_traffic(tag) if (pf_out is pf and args.range_src == "tv") else None
+        chain = "lut3d" if pf.family != "yuv" else (
+            ("scale=in_range=pc:out_range=tv,format=8-bit -> " if full_range else "") + "yuv->rgb -> lut3d -> rgb->yuv")
         result = {
             "metric": "Mpixels/s (+ achieved HBM GB/s %peak), UHD 10-bit tetrahedral, 1/2/4/8 MI355X",
             "value": round(px_total * args.steps / wall / 1e6, 1),
@@ -341,26 +457,35 @@ def main():
             "dtype": "f32",
             "data": f"synthetic ({args.dist}: {args.unique} seeded frames tiled to the batch; generated log709 .cube)",
             "config": {
-                "workload": f"{w}x{h} {args.fmt}, {args.lut}^3 log->Rec.709 .cube, {args.interp}, "
-                            f"{args.frames} frames/GPU/step resident in HBM, row-block shard x{world}",
+                "workload": f"{w}x{h} {args.fmt}" + (f" -> {args.out_fmt}" if pf_out is not pf else "") +
+                            f", {args.lut}^3 log->Rec.709 .cube, {args.interp}, {args.frames} frames/GPU/step resident in HBM, "
+                            f"row-block shard x{world} (rows [{r0},{r1}) of shared full-height planes on rank 0)",
                 "frames_per_gpu": args.frames, "lut_size": args.lut, "interp": args.interp,
-                "pix_fmt": args.fmt, "distribution": args.dist, "kernel": kernel_name, "lds_window": tile_stats,
+                "pix_fmt": args.fmt, "out_pix_fmt": args.out_fmt or args.fmt, "range_src": args.range_src,
+                "chain": chain, "precision": args.precision,
+                "distribution": args.dist, "kernel": kernel_name, "lds_window": tile_stats,
                 "dither": args.dither,
                 "parallelism": f"row-block x{world}", "bytes_per_pixel": bpp,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(tag),
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": ("profiles/traffic.json: committed rocprofv3 --pmc summary of this workload "
+                                   "(FETCH_SIZE x2 + WRITE_SIZE), NOT measured in this run") if traffic else None,
                 "kernel_ms": round(kern * 1e3, 4), "algorithmic_bytes_per_launch": int(bytes_launch),
                 "read_GBps": round((bpp_in * px_rank + lattice_bytes) / kern / 1e9, 1),
             },
         }
+        if collective:
+            result["collective"] = collective
+        if strong:
+            result["strong"] = strong
         if extra:
             result["extra_Mpx_s"] = extra
         if host_pipe:
             result["host_pipeline"] = host_pipe
         if not args.no_cpu_baseline and world == 1 and pf.family != "packed":
-            result["cpu_baseline"] = cpu_baseline(lut, pf, w, h, args.interp, args.dist, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(lut, job, w, h, args.interp, args.dist, args.cpu_seconds)
         elif world > 1:
             result["cpu_baseline"] = None          # timed on rank 0 at N=1 only
         print(json.dumps(result), flush=True)

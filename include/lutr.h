@@ -158,7 +158,9 @@ int  lutr_ctx_create(int device, lutr_ctx **out);
 void lutr_ctx_destroy(lutr_ctx *ctx);
 /* run on a caller-owned HIP stream (hipStream_t passed as void*); NULL selects HIP's default
  * (null) stream, which is what torch.cuda.current_stream() is unless the caller changed it.
- * Until this is called the context uses a private non-blocking stream. */
+ * Until this is called the context uses a private non-blocking stream.  Launches of one context never
+ * overlap: if work issued on the previous stream may still be running, the new stream is made to wait
+ * for it (hipStreamWaitEvent) -- the context's work queue and scratch are per context, not per stream. */
 int  lutr_ctx_set_stream(lutr_ctx *ctx, void *hip_stream);
 int  lutr_ctx_sync(lutr_ctx *ctx);
 
@@ -174,6 +176,13 @@ int  lutr_ctx_lut_device(lutr_ctx *ctx, void **dptr, size_t *bytes);
  * records the lattice's value range, which selects clip-free kernels for lattices inside [0, 1].
  * Optional: an unsealed lattice is applied with the general kernels. */
 int  lutr_ctx_lut_seal(lutr_ctx *ctx);
+/* One process, several GPUs (the reference is one GUI process with a thread pool,
+ * src/lut_renderer/task_manager.py:229-235, so it cannot start one rank per GPU): copy the lattice of
+ * ctxs[root] into every other context, GPU to GPU over xGMI (hipMemcpyPeerAsync on each receiver's stream;
+ * a plain device copy when two contexts share a GPU).  Receivers are allocated as needed and inherit the
+ * root's value-range seal.  Asynchronous: each context's later applies are ordered behind its copy.  This
+ * is the single-process twin of the RCCL broadcast one-rank-per-GPU hosts do into lutr_ctx_lut_device. */
+int  lutr_lut_broadcast(lutr_ctx **ctxs, int nctx, int root);
 /* bytes of the device lattice layout for size n: (n+1)^3 nodes of 16 bytes */
 size_t lutr_lattice_bytes(int n);
 

@@ -14,4 +14,10 @@ def __getattr__(name):
     if name in ("LutEngine", "parse_pix_fmt", "yuv_constants"):
         from . import engine
         return getattr(engine, name)
+    if name == "LutEngineGroup":
+        from . import multigpu
+        return multigpu.LutEngineGroup
+    if name == "apply_lut":
+        from . import api
+        return api.apply_lut
     raise AttributeError(name)

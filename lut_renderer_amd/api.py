@@ -29,6 +29,33 @@ from .plan import LutPlan, output_color_tags, resolve_lut_plan
 _ENGINE_INTERP = ("nearest", "trilinear", "tetrahedral", "pyramid", "prism")
 
 _lut_cache: Dict[Tuple[str, float, int], CubeLut] = {}
+# engines apply_lut creates for itself, kept per device tuple: a context holds a stream, the device lattice and the
+# kernels' work queue, and the reference calls the path once per task, not once per frame
+_engine_cache: Dict[Tuple[int, ...], object] = {}
+
+
+def _cached_engine(devices: Tuple[int, ...]):
+    from .engine import LutEngine
+    from .multigpu import LutEngineGroup
+    eng = _engine_cache.get(devices)
+    if eng is None:
+        eng = LutEngine(devices[0]) if len(devices) == 1 else LutEngineGroup(devices)
+        _engine_cache[devices] = eng
+    return eng
+
+
+def close_cached_engines() -> None:
+    """Destroy the contexts `apply_lut` keeps between calls (also registered with atexit)."""
+    for eng in _engine_cache.values():
+        try:
+            eng.close()
+        except Exception:
+            pass
+    _engine_cache.clear()
+
+
+import atexit  # noqa: E402
+atexit.register(close_cached_engines)
 
 
 def _cached_cube(path: Path) -> CubeLut:
@@ -71,9 +98,14 @@ def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: s
     engine's device, each [H,W] or [F,H,W].  Returns (planes_out, tags) where `tags` is the colour
     metadata the reference would write for this policy (None = inherit / none).
 
-    `engine` may be a LutEngine that already holds the lattice (then `cube` may be None);
-    otherwise one is created on devices[0] for the call."""
-    from .engine import LutEngine
+    `engine` may be a LutEngine (or LutEngineGroup) that already holds the lattice (then `cube` may be
+    None).  Otherwise `devices` names the GPUs: one device -> one context; several -> a LutEngineGroup that
+    splits the rows of every frame over them inside this one process (lattice copied GPU to GPU, one launch
+    per device, no host wait between launches).  Contexts made here are kept for the next call
+    (`close_cached_engines`)."""
+    devices = tuple(int(d) for d in devices)
+    if not devices:
+        raise ValueError("devices must name at least one GPU")
     if width is not None and planes[0].shape[-1] != width or height is not None and planes[0].shape[-2] != height:
         raise ValueError("plane shape does not match width/height")
     params = ProcessingParams(lut_interp=interp, lut_input_matrix=input_matrix, lut_output_tags=output_tags,
@@ -85,14 +117,13 @@ def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: s
     # ffmpeg.py:305-307: any value other than "error_diffusion" leaves the chain without a dither filter
     kw["dither"] = "error_diffusion" if getattr(params, "zscale_dither", "none") == "error_diffusion" else "none"
     own = engine is None
-    eng = engine or LutEngine(devices[0])
-    try:
-        if cube is not None:
-            eng.set_lut(cube if isinstance(cube, CubeLut) else _cached_cube(Path(cube)))
-        result = eng.apply_yuv(planes, out, **kw)
-        if own:
-            eng.sync()
-    finally:
-        if own:
-            eng.close()
+    eng = engine if engine is not None else _cached_engine(devices)
+    if cube is not None:
+        lut = cube if isinstance(cube, CubeLut) else _cached_cube(Path(cube))
+        if getattr(eng, "_applied_lut", None) is not lut:        # same parsed LUT as last time: the device copy stands
+            eng.set_lut(lut)
+            eng._applied_lut = lut
+    result = eng.apply_yuv(planes, out, **kw)
+    if own:
+        eng.sync()
     return result, output_color_tags(plan.output_policy)

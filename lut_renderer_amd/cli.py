@@ -28,7 +28,7 @@ def _hms(seconds: float) -> str:
     return f"{int(h):02d}:{int(m):02d}:{s:05.2f}"
 
 
-def main(argv=None) -> int:
+def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="lut_renderer_amd.cli", description=__doc__.split("\n\n")[0])
     ap.add_argument("-i", "--input", required=True)
     ap.add_argument("-o", "--output", required=True)
@@ -46,29 +46,39 @@ def main(argv=None) -> int:
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("-y", action="store_true", help="overwrite the output (ffmpeg's -y)")
-    args = ap.parse_args(argv)
+    return ap
+
+
+def plan_from_args(args):
+    """The LutPlan and engine call the options select -- the same resolution `build_command` performs (plan.py)."""
+    from .api import engine_call_for
+    from .params import ProcessingParams, VideoInfo, infer_bit_depth
+    from .plan import resolve_lut_plan
+    w, h = (int(v) for v in args.size.lower().split("x"))
+    params = ProcessingParams(lut_interp=args.interp, lut_input_matrix=args.input_matrix,
+                              lut_output_tags=args.output_tags, zscale_dither=args.zscale_dither)
+    info = VideoInfo(width=w, height=h, pix_fmt=args.pix_fmt, bit_depth=infer_bit_depth(args.pix_fmt),
+                     colorspace=args.colorspace, color_range=args.color_range)
+    plan = resolve_lut_plan(params, args.cube, info)
+    kw = engine_call_for(plan, args.pix_fmt, args.out_pix_fmt)
+    if args.zscale_dither == "error_diffusion":
+        kw["dither"] = "error_diffusion"
+    return plan, kw, w, h
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
 
     stop = {"flag": False}
     signal.signal(signal.SIGTERM, lambda *_: stop.__setitem__("flag", True))
     try:
-        w, h = (int(v) for v in args.size.lower().split("x"))
         if os.path.exists(args.output) and not args.y:
             raise FileExistsError(f"{args.output} exists (pass -y to overwrite)")
-        from .api import engine_call_for
+        plan, kw, w, h = plan_from_args(args)
         from .cube import read_lut
         from .engine import LutEngine
-        from .params import ProcessingParams, VideoInfo, infer_bit_depth
-        from .plan import resolve_lut_plan
         from .stream import HostPipeline
 
-        params = ProcessingParams(lut_interp=args.interp, lut_input_matrix=args.input_matrix,
-                                  lut_output_tags=args.output_tags, zscale_dither=args.zscale_dither)
-        info = VideoInfo(width=w, height=h, pix_fmt=args.pix_fmt, bit_depth=infer_bit_depth(args.pix_fmt),
-                         colorspace=args.colorspace, color_range=args.color_range)
-        plan = resolve_lut_plan(params, args.cube, info)
-        kw = engine_call_for(plan, args.pix_fmt, args.out_pix_fmt)
-        if args.zscale_dither == "error_diffusion":
-            kw["dither"] = "error_diffusion"
         eng = LutEngine(args.device)
         eng.set_lut(read_lut(args.cube))
         pix_fmt, out_fmt = kw.pop("pix_fmt"), kw.pop("out_pix_fmt")

@@ -245,3 +245,47 @@ def build_pipeline(task: Task, ffmpeg_bin: str = "ffmpeg") -> List[CommandStage]
         CommandStage("分发编码", task.intermediate_path, task.output_path, params, lut_path=None,
                      probe_source=True),
     ]
+
+
+# ---------------------------------------------------------------- engine twin
+def engine_command(source: Path, output: Path, params: ProcessingParams, lut_path: Path,
+                   source_info: VideoInfo, python_bin: Optional[str] = None, device: int = 0,
+                   notes: Optional[List[str]] = None) -> List[str]:
+    """`build_command`'s twin for the LUT stage alone: the argv of the ENGINE CLI (`python -m lut_renderer_amd.cli`)
+    that applies exactly the chain `build_command` would put into `-vf` -- the same `LutPlan`, rendered as CLI options
+    instead of as a filter string (ffmpeg.py:195-247, :287-310).  `source` / `output` are rawvideo files (or `-`) in
+    `source_info.pix_fmt` and the pixel format `resolve_pix_fmt` picks; `task_manager.py:145-151` can Popen the result
+    unchanged (same `Duration:` / `time=` / exit-code / SIGTERM contract).  `notes` receives the plan's notes, like
+    `build_command`'s out-parameter.  The copy guard of ffmpeg.py:255-256 applies: a LUT stage cannot be a stream copy."""
+    import sys as _sys
+    if lut_path is None:
+        raise ValueError("engine_command renders the LUT stage: lut_path is required")
+    if source_info is None or not source_info.pix_fmt or not source_info.width or not source_info.height:
+        raise ValueError("engine_command needs source_info with pix_fmt, width and height (raw frames carry no header)")
+    if params.video_codec == "copy":
+        raise ValueError("启用 LUT/滤镜时不能使用视频 copy（streamcopy 与滤镜不可同时使用）。")
+    notes = notes if notes is not None else []
+    plan = resolve_lut_plan(params, lut_path, source_info)
+    notes.extend(plan.notes)
+    cmd = [python_bin or _sys.executable, "-m", "lut_renderer_amd.cli"]
+    if params.overwrite:
+        cmd.append("-y")
+    cmd += ["-i", str(source), "-o", str(output), "--size", f"{source_info.width}x{source_info.height}",
+            "--pix-fmt", source_info.pix_fmt]
+    pix_fmt = resolve_pix_fmt(params, source_info, notes) if params.video_codec else ""
+    if pix_fmt:
+        cmd += ["--out-pix-fmt", pix_fmt]
+    cmd += ["--cube", str(plan.lut_path), "--interp", plan.interp, "--input-matrix", plan.matrix_policy,
+            "--output-tags", plan.output_policy]
+    if getattr(params, "zscale_dither", "none") == "error_diffusion" and pix_fmt:
+        cmd += ["--zscale-dither", "error_diffusion"]
+        notes.append("抖动: zscale=dither=error_diffusion")
+    if source_info.colorspace:
+        cmd += ["--colorspace", str(source_info.colorspace)]
+    if source_info.color_range:
+        cmd += ["--color-range", str(source_info.color_range)]
+    if source_info.fps:
+        cmd += ["--fps", f"{float(source_info.fps):g}"]
+    if device:
+        cmd += ["--device", str(int(device))]
+    return cmd

@@ -124,7 +124,9 @@ extern "C" int lutr_cube_parse(const char *path, float **rgb, int *n, float scal
     }
 
     for (int c = 0; c < 3; c++) {
-        float s = (float)(1.0 / ((double)dmax[c] - (double)dmin[c]));
+        // vf_lut3d.c: av_clipf(1. / (max[c] - min[c]), 0.f, 1.f): float subtraction, double division, float clip
+        const float span = dmax[c] - dmin[c];
+        float s = (float)(1.0 / (double)span);
         if (!(s == s)) s = 0.f;
         s = s < 0.f ? 0.f : s;
         s = s > 1.f ? 1.f : s;

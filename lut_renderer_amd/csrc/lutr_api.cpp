@@ -169,6 +169,11 @@ struct lutr_ctx {
     float *fscratch = nullptr;       // float planes of the dither path
     size_t fscratch_floats = 0;
     unsigned *stats = nullptr;       // 8 device counters (4 reported + clock stamps), see lutr_ctx_tile_stats
+    // The queue counter, the dither scratch and the stats block are per context, not per stream: launches of one
+    // context must not overlap.  Every launch records `done` on the stream it ran on; binding another stream makes
+    // that stream wait for it (lutr_ctx_set_stream), so applies issued from different streams serialise on the GPU.
+    hipEvent_t done = nullptr;
+    bool pending = false;            // `done` was recorded on `stream` and nothing has waited for it yet
 };
 
 extern "C" {
@@ -229,6 +234,13 @@ int lutr_ctx_create(int device, lutr_ctx **out)
         delete c;
         return hip_fail(e, "hipMalloc(queue)");
     }
+    e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipFree(c->queue);
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return hip_fail(e, "hipEventCreateWithFlags");
+    }
     *out = c;
     return LUTR_OK;
 }
@@ -241,6 +253,7 @@ void lutr_ctx_destroy(lutr_ctx *c)
     if (c->stats) (void)hipFree(c->stats);
     if (c->fscratch) (void)hipFree(c->fscratch);
     if (c->queue) (void)hipFree(c->queue);
+    if (c->done) (void)hipEventDestroy(c->done);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -248,7 +261,14 @@ void lutr_ctx_destroy(lutr_ctx *c)
 int lutr_ctx_set_stream(lutr_ctx *c, void *hip_stream)
 {
     if (!c) { set_error("null context"); return LUTR_EINVAL; }
-    c->stream = (hipStream_t)hip_stream;   // NULL is HIP's default (null) stream, e.g. torch's default
+    hipStream_t next = (hipStream_t)hip_stream;   // NULL is HIP's default (null) stream, e.g. torch's default
+    if (next != c->stream && c->pending) {
+        // work of this context may still be running on the old stream, and it owns the context's queue counter and
+        // scratch: the new stream starts behind it
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamWaitEvent(next, c->done, 0));
+    }
+    c->stream = next;
     return LUTR_OK;
 }
 
@@ -387,6 +407,32 @@ int lutr_ctx_lut_seal(lutr_ctx *c)
     return LUTR_OK;
 }
 
+int lutr_lut_broadcast(lutr_ctx **ctxs, int nctx, int root)
+{
+    if (!ctxs || nctx < 1 || root < 0 || root >= nctx) { set_error("lutr_lut_broadcast: bad arguments"); return LUTR_EINVAL; }
+    for (int i = 0; i < nctx; i++)
+        if (!ctxs[i]) { set_error("lutr_lut_broadcast: null context %d", i); return LUTR_EINVAL; }
+    lutr_ctx *r = ctxs[root];
+    if (!r->lat) { set_error("the root context holds no lattice"); return LUTR_EINVAL; }
+    // the root's upload (a blocking copy) has landed; order the peers' copies behind whatever the root's stream still runs
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipEventRecord(r->done, r->stream));
+    r->pending = true;
+    for (int i = 0; i < nctx; i++) {
+        lutr_ctx *c = ctxs[i];
+        if (c == r) continue;
+        int rc = alloc_lattice(c, r->n, r->scale);        // selects c's device
+        if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(c->stream, r->done, 0));
+        if (c->device == r->device)
+            HIP_TRY(hipMemcpyAsync(c->lat, r->lat, r->lat_bytes, hipMemcpyDeviceToDevice, c->stream));
+        else
+            HIP_TRY(hipMemcpyPeerAsync(c->lat, c->device, r->lat, r->device, r->lat_bytes, c->stream));   // xGMI, GPU to GPU
+        c->unit = r->unit;           // same nodes: the root's scan of the value range holds for the copy
+    }
+    return LUTR_OK;
+}
+
 int lutr_ctx_lut_device(lutr_ctx *c, void **dptr, size_t *bytes)
 {
     if (!c || !dptr || !bytes) { set_error("null argument"); return LUTR_EINVAL; }
@@ -445,6 +491,8 @@ static int finish_launch(lutr_ctx *c, const char *name)
     c->last_kernel = name;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, name);
+    HIP_TRY(hipEventRecord(c->done, c->stream));
+    c->pending = true;
     return LUTR_OK;
 }
 

@@ -37,10 +37,19 @@ struct Rgb { float r, g, b; };
 
 __device__ __forceinline__ float lerpf(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
 
+// FFmpeg's NEAR(x) = (int)(x + .5) adds a DOUBLE .5 to the float coordinate, so the sum is exact and the result is
+// floor(x) + (frac(x) >= 1/2).  frac(x) = x - floor(x) is exact in fp32, which makes this form bit-identical without
+// double arithmetic (floorf(x + .5f) is not: for x = k + 0.49999997 the float sum rounds up to k + 1).
+__device__ __forceinline__ float near_f(float s)
+{
+    const float p = floorf(s);
+    return (s - p >= .5f) ? p + 1.0f : p;
+}
+
 template <class F>
 __device__ __forceinline__ Rgb interp_nearest(const F &f, float sr, float sg, float sb)
 {
-    const float4 c = f.ld(f.index(floorf(sr + .5f), floorf(sg + .5f), floorf(sb + .5f)));
+    const float4 c = f.ld(f.index(near_f(sr), near_f(sg), near_f(sb)));
     return Rgb{c.x, c.y, c.z};
 }
 

@@ -2,6 +2,18 @@
 // gfx950 kernels (lutr_kernels.hip).  Not part of the public boundary.
 #pragma once
 
+#ifdef LUTR_HOST_ONLY
+// Sanitizer build of the two host parsers (oracle/Makefile `asan`: gcc -fsanitize=address,undefined, no HIP):
+// they need the public header and set_error only.
+#include <stdint.h>
+
+#include "lutr.h"
+
+namespace lutr {
+void set_error(const char *fmt, ...);
+}
+#else
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -90,3 +102,4 @@ int make_yuv_consts(const lutr_yuv_params &p, YuvConsts *out);
 void set_error(const char *fmt, ...);
 
 }  // namespace lutr
+#endif  // LUTR_HOST_ONLY

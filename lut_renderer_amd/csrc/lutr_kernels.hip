@@ -188,8 +188,10 @@ static inline bool aligned_to(const void *p, long long a) { return ((uintptr_t)p
 static bool planes_aligned(const PlaneSet &P, int plane, long long a, bool batch)
 {
     // the fast kernels address rows with 32-bit positive offsets; bottom-up (negative linesize) or
-    // huge strides go to the generic kernel, which does 64-bit signed arithmetic
-    if (P.ss[plane] <= 0 || P.ds[plane] <= 0 || P.ss[plane] > 0x3fffffff || P.ds[plane] > 0x3fffffff) return false;
+    // huge strides go to the generic kernel, which does 64-bit signed arithmetic.  A tile kernel forms
+    // (row in tile) * stride + 16 * (unit in row) as one unsigned 32-bit offset with up to 31 rows and 63 units.
+    constexpr long long kMaxStride = (0xffffffffll - 64 * 16) / 32;
+    if (P.ss[plane] <= 0 || P.ds[plane] <= 0 || P.ss[plane] > kMaxStride || P.ds[plane] > kMaxStride) return false;
     if (!aligned_to(P.s[plane], a) || !aligned_to(P.d[plane], a)) return false;
     if (P.ss[plane] % a || P.ds[plane] % a) return false;
     if (batch && (P.sfs[plane] % a || P.dfs[plane] % a)) return false;

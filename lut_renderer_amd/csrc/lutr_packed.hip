@@ -115,6 +115,8 @@ const char *launch_packed(hipStream_t st, int variant, const LutConsts &L, const
                   G.w % 4 == 0 && px / 4 < 0x7fffffffll && mult4((long long)(uintptr_t)P.s) &&
                   mult4((long long)(uintptr_t)P.d) && mult4(P.ss) && mult4(P.ds) &&
                   (G.nframes == 1 || (mult4(P.sfs) && mult4(P.dfs)));
+    // the 3-component vector body knows RGB and BGR order only; any other permutation takes the scalar kernel
+    if (nc == 3 && !(P.go == 1 && ((P.ro == 0 && P.bo == 2) || (P.ro == 2 && P.bo == 0)))) vec_ok = false;
     if (variant == VAR_GENERIC) vec_ok = false;
     if (!vec_ok) {
         if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;

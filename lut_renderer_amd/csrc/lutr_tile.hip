@@ -213,7 +213,11 @@ __device__ __forceinline__ Crd crd_compute(const LutConsts &L, float code, float
     // plain v_min_f32 (full rate) replaces v_med3_f32 (0.62x rate on gfx950, tools/ubench/op_rates.hip)
     const float s = fminf(x * sc, L.lut_max);
     Crd c;
-    if constexpr (INTERP == LUTR_INTERP_NEAREST) { c.p = floorf(s + .5f); c.d = 0.0f; }
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) {     // NEAR(x) with FFmpeg's double .5 (near_f, lutr_device.h)
+        const float fl = floorf(s);
+        c.p = (s - fl >= .5f) ? fl + 1.0f : fl;
+        c.d = 0.0f;
+    }
     else { c.p = floorf(s); c.d = s - c.p; }
     return c;
 }

@@ -67,6 +67,24 @@ def parse_pix_fmt(name: str) -> PixFmt:
     return PixFmt(name, "yuv", depth_i, csx, csy, fam == "yuvj")
 
 
+def _check_planes(planes: Sequence[torch.Tensor], fmt: PixFmt, w: int, h: int, what: str) -> None:
+    """The C-ABI takes bare pointers and cannot know buffer sizes: every plane must have exactly the shape and the
+    element size `fmt` implies for a w x h frame, or the kernels would read or write outside it."""
+    if len(planes) != 3:
+        raise ValueError("expected three planes")
+    esize = 1 if fmt.depth <= 8 else 2
+    for i, t in enumerate(planes):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("planes must be torch tensors resident on the engine's GPU")
+        if t.dim() not in (2, 3):
+            raise ValueError("planes must be [H,W] or [F,H,W]")
+        if t.is_floating_point() or t.element_size() != esize:
+            raise ValueError(f"{what} plane {i}: '{fmt.name}' takes {8 * esize}-bit integer samples, got {t.dtype}")
+        want = fmt.plane_shape(i, w, h)
+        if tuple(t.shape[-2:]) != want:
+            raise ValueError(f"{what} plane {i} is {tuple(t.shape[-2:])}, '{fmt.name}' at {w}x{h} needs {want}")
+
+
 def _planes_struct(planes: Sequence[torch.Tensor], device: torch.device) -> Tuple[_native.Planes, int]:
     """Describe three [H,W] or [F,H,W] tensors as struct lutr_planes; returns (struct, nframes)."""
     if len(planes) != 3:
@@ -201,7 +219,12 @@ class LutEngine:
         """lut3d on planar RGB; planes in gbrp order (G, B, R), each [H,W] or [F,H,W]."""
         if dst is None:
             dst = [torch.empty_like(t) for t in src]
+        if not 8 <= int(depth) <= 16:
+            raise ValueError(f"unsupported depth {depth}")
         h, w = src[0].shape[-2], src[0].shape[-1]
+        fmt = PixFmt(f"gbrp{depth}", "gbr", int(depth), 0, 0, True)
+        _check_planes(src, fmt, w, h, "source")
+        _check_planes(dst, fmt, w, h, "destination")
         s, nf = _planes_struct(src, self.device)
         d, nfd = _planes_struct(dst, self.device)
         if nf != nfd:
@@ -272,6 +295,8 @@ class LutEngine:
             dt = torch.uint8 if fout.depth <= 8 else src[0].dtype if src[0].element_size() == 2 else torch.int16
             lead = tuple(src[0].shape[:-2])
             dst = [torch.empty(lead + fout.plane_shape(i, w, h), dtype=dt, device=self.device) for i in range(3)]
+        _check_planes(src, fin, w, h, "source")
+        _check_planes(dst, fout, w, h, "destination")
         s, nf = _planes_struct(src, self.device)
         d, nfd = _planes_struct(dst, self.device)
         if nf != nfd:

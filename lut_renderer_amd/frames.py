@@ -93,7 +93,7 @@ def uniform_rgb(w: int, h: int, depth: int = 10, k: int = 0) -> List[np.ndarray]
     return [rng.integers(0, m + 1, size=(h, w), dtype=np.int64).astype(_dtype(depth)) for _ in range(3)]
 
 
-def natural_rgb(w: int, h: int, depth: int = 10, k: int = 0) -> List[np.ndarray]:
+def natural_rgb(w: int, h: int, depth: int = 10, k: int = 0, noise_sigma_10bit: float = 2.0) -> List[np.ndarray]:
     """gbrp order (G, B, R): a grey-ish gradient with per-channel tint, patches and noise."""
     rng = np.random.default_rng(SEED_BASE + k)
     m = (1 << depth) - 1
@@ -106,9 +106,21 @@ def natural_rgb(w: int, h: int, depth: int = 10, k: int = 0) -> List[np.ndarray]
         mask = np.clip((1.0 - np.maximum(np.abs(xx - px) / rx, np.abs(yy - py) / ry)) / 0.08, 0.0, 1.0)
         for c in chans:
             c += rng.uniform(-0.2, 0.2) * mask
-    sig = 2.0 * float(1 << depth) / 1024.0
+    sig = noise_sigma_10bit * float(1 << depth) / 1024.0
     return [np.clip(np.rint(np.clip(c, 0, 1) * m + rng.normal(0.0, sig, size=(h, w))), 0, m).astype(_dtype(depth))
             for c in chans]
+
+
+def _noise_sigma(dist: str) -> float:
+    """"noise<S>": the natural frame with luma AND per-sample chroma noise of sigma S codes (10-bit scale) instead of 2
+    -- the range between clean footage and the uniform worst case (S = 16 is half a 33^3 lattice cell, 64 two cells)."""
+    try:
+        s = float(dist[5:])
+    except ValueError:
+        raise ValueError(f"unknown distribution '{dist}'") from None
+    if not 0.0 <= s <= 1024.0:
+        raise ValueError(f"unknown distribution '{dist}'")
+    return s
 
 
 def make_yuv(dist: str, w: int, h: int, depth: int, csx: int, csy: int, k: int = 0,
@@ -117,4 +129,17 @@ def make_yuv(dist: str, w: int, h: int, depth: int, csx: int, csy: int, k: int =
         return uniform_yuv(w, h, depth, csx, csy, k, full_range)
     if dist == "natural":
         return natural_yuv(w, h, depth, csx, csy, k, full_range)
+    if dist.startswith("noise"):
+        return natural_yuv(w, h, depth, csx, csy, k, full_range, noise_sigma_10bit=_noise_sigma(dist))
+    raise ValueError(f"unknown distribution '{dist}'")
+
+
+def make_rgb(dist: str, w: int, h: int, depth: int, k: int = 0) -> List[np.ndarray]:
+    """gbrp order (G, B, R)."""
+    if dist == "uniform":
+        return uniform_rgb(w, h, depth, k)
+    if dist == "natural":
+        return natural_rgb(w, h, depth, k)
+    if dist.startswith("noise"):
+        return natural_rgb(w, h, depth, k, noise_sigma_10bit=_noise_sigma(dist))
     raise ValueError(f"unknown distribution '{dist}'")

@@ -53,7 +53,8 @@ def parse_cube_text(text: str):
             raise ValueError("EILSEQ")
     arr = np.array(vals, dtype=F).reshape(n, n, n, 3)        # file index [b][g][r]
     table = np.ascontiguousarray(np.transpose(arr, (2, 1, 0, 3)))
-    scale = np.array([np.clip(F(1.0 / (float(F(dmax[c])) - float(F(dmin[c])))), 0, 1) for c in range(3)], dtype=F)
+    # float subtraction, double division, float clip (vf_lut3d.c parse_cube)
+    scale = np.array([np.clip(F(1.0 / float(F(dmax[c]) - F(dmin[c]))), 0, 1) for c in range(3)], dtype=F)
     return n, scale, table
 
 
@@ -67,7 +68,8 @@ def _interp(table, mode, s):
     n = table.shape[0]
     sr, sg, sb = s
     if mode == "nearest":
-        i = [(v + F(0.5)).astype(np.int32) for v in (sr, sg, sb)]
+        # NEAR(x) = (int)(x + .5) with a double .5: the sum is exact in double
+        i = [(v.astype(np.float64) + 0.5).astype(np.int32) for v in (sr, sg, sb)]
         return table[i[0], i[1], i[2]]
     p = [v.astype(np.int32) for v in (sr, sg, sb)]
     x = [np.minimum(v + 1, n - 1) for v in p]

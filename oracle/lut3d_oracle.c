@@ -135,7 +135,10 @@ int orc_cube_parse(const char *path, orc_lut *out)
     }
     /* scale = clip(1/(max-min), 0, 1); min is never subtracted from the input (A.2) */
     for (int c = 0; c < 3; c++) {
-        float s = (float)(1.0 / ((double)max[c] - (double)min[c]));
+        /* vf_lut3d.c: av_clipf(1. / (max[c] - min[c]), 0.f, 1.f) -- the subtraction is float - float (C evaluates it
+         * in float), the division is double (the literal 1. is a double), the clip's parameter makes it float again */
+        const float span = max[c] - min[c];
+        float s = (float)(1.0 / (double)span);
         if (s < 0.f) s = 0.f;     /* av_clipf(x, 0, 1) = min(max(x,0),1) */
         if (s > 1.f) s = 1.f;
         if (s != s) s = 0.f;      /* NaN from 0/0 domain: treat as degenerate */
@@ -372,7 +375,9 @@ static inline rgbvec node(const orc_lut *l, int r, int g, int b)
 
 #define PREV(x) ((int)(x))
 #define NEXT(x, n) (((int)(x) + 1) < (n) - 1 ? ((int)(x) + 1) : (n) - 1)
-#define NEAR(x) ((int)((x) + .5f))
+/* vf_lut3d.c: #define NEAR(x) ((int)((x) + .5)) -- .5 is a double literal, so the float coordinate is promoted and the
+ * sum is exact; with .5f the sum would round up to the next integer for x = k + 0.49999997 (the float below k + 1/2). */
+#define NEAR(x) ((int)((double)(x) + .5))
 
 static inline float lerpf(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
 

@@ -1,0 +1,116 @@
+"""Host-side additions of round 2 (no GPU): plane validation ahead of the C-ABI, the engine twin of build_command,
+the noise-swept frame generator."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from lut_renderer_amd import frames
+from lut_renderer_amd.command import build_command, engine_command
+from lut_renderer_amd.engine import _check_planes, parse_pix_fmt
+from lut_renderer_amd.params import ProcessingParams, VideoInfo
+
+
+def _planes(fmt, w, h, dtype=None, nframes=None):
+    pf = parse_pix_fmt(fmt)
+    dt = dtype or (torch.uint8 if pf.depth <= 8 else torch.int16)
+    lead = () if nframes is None else (nframes,)
+    return pf, [torch.zeros(lead + pf.plane_shape(i, w, h), dtype=dt) for i in range(3)]
+
+
+def test_plane_validation_accepts_what_the_format_implies():
+    for fmt in ("yuv420p", "yuv420p10le", "yuv422p10le", "yuv444p12le", "gbrp10le"):
+        pf, planes = _planes(fmt, 64, 36)
+        _check_planes(planes, pf, 64, 36, "source")
+        pf, planes = _planes(fmt, 65, 37, nframes=3)              # odd sizes: chroma planes round up
+        _check_planes(planes, pf, 65, 37, "source")
+
+
+def test_plane_validation_rejects_what_would_run_off_the_buffers():
+    """The C-ABI takes bare pointers (include/lutr.h): a wrong element size or a short chroma plane would make the
+    kernels read or write outside the tensors, so the Python layer refuses them before any call into liblutr."""
+    pf, planes = _planes("yuv420p10le", 64, 36, dtype=torch.uint8)       # 8-bit tensors named as a 10-bit format
+    with pytest.raises(ValueError, match="16-bit"):
+        _check_planes(planes, pf, 64, 36, "source")
+    pf, planes = _planes("yuv420p", 64, 36, dtype=torch.int16)
+    with pytest.raises(ValueError, match="8-bit"):
+        _check_planes(planes, pf, 64, 36, "destination")
+    pf, planes = _planes("yuv420p10le", 64, 36)
+    planes[1] = planes[1][:-1]                                           # chroma plane one row short
+    with pytest.raises(ValueError, match="plane 1"):
+        _check_planes(planes, pf, 64, 36, "source")
+    pf, planes = _planes("yuv422p", 64, 36)
+    planes[2] = torch.zeros((36, 64), dtype=torch.uint8)                 # 4:4:4 sized plane in a 4:2:2 frame
+    with pytest.raises(ValueError, match="plane 2"):
+        _check_planes(planes, pf, 64, 36, "source")
+    pf, planes = _planes("yuv420p", 64, 36)
+    with pytest.raises(ValueError):
+        _check_planes(planes[:2], pf, 64, 36, "source")
+    with pytest.raises(ValueError):
+        _check_planes([p.float() for p in planes], pf, 64, 36, "source")
+    with pytest.raises(TypeError):
+        _check_planes([p.numpy() for p in planes], pf, 64, 36, "source")
+
+
+PC = VideoInfo(width=1920, height=1080, bit_depth=8, pix_fmt="yuvj420p", color_range="pc", colorspace="bt709", fps=25.0)
+PC10 = VideoInfo(width=1920, height=1080, bit_depth=10, pix_fmt="yuv422p10le", color_range="pc", colorspace="bt2020nc")
+TV10 = VideoInfo(width=3840, height=2160, bit_depth=10, pix_fmt="yuv420p10le", color_range="tv", colorspace="bt2020nc", fps=24.0)
+
+
+@pytest.mark.parametrize("info,kw", [
+    (PC, dict(video_codec="libx265")),
+    (PC, dict(video_codec="libx265", lut_output_tags="inherit")),
+    (PC10, dict(video_codec="libx265", lut_input_matrix="none")),
+    (TV10, dict(video_codec="libx265")),
+    (TV10, dict(video_codec="libx265", lut_input_matrix="bt709", lut_interp="trilinear")),
+    (TV10, dict(video_codec="libx264")),                                                   # App. D case K: 10 -> 8 bit
+    (TV10, dict(video_codec="libx264", bit_depth_policy="force_8bit", zscale_dither="error_diffusion")),
+    (TV10, dict(video_codec="prores_ks")),
+    (TV10, dict(video_codec="libx265", lut_interp="bogus")),
+])
+def test_engine_command_renders_the_same_plan_as_build_command(info, kw):
+    """The engine CLI's argv, parsed back by the CLI's own parser, resolves to the filter chain build_command puts into
+    -vf (ffmpeg.py:195-247) and to the pixel format it passes as -pix_fmt (ffmpeg.py:287-310)."""
+    from lut_renderer_amd import cli
+    params = ProcessingParams(**kw)
+    notes_f, notes_e = [], []
+    ff = build_command(Path("in.mov"), Path("out.mp4"), params, lut_path=Path("l u't/look.cube"), source_info=info,
+                       notes=notes_f)
+    cmd = engine_command(Path("in.yuv"), Path("out.yuv"), params, Path("l u't/look.cube"), info, python_bin="python3",
+                         notes=notes_e)
+    assert cmd[:3] == ["python3", "-m", "lut_renderer_amd.cli"] and cmd[0:1] == ["python3"]
+    args = cli.build_parser().parse_args(cmd[3:])
+    plan, call, w, h = cli.plan_from_args(args)
+    vf = ff[ff.index("-vf") + 1].split(",")
+    n = next(i for i, f in enumerate(vf) if f.startswith("lut3d=")) + 1
+    assert plan.filters() == vf[:n]
+    assert (w, h) == (info.width, info.height)
+    if "-pix_fmt" in ff:
+        assert call["out_pix_fmt"] == ff[ff.index("-pix_fmt") + 1]
+    assert ("zscale=dither=error_diffusion" in vf) == (call.get("dither") == "error_diffusion")
+    keep = lambda ns: [x for x in ns if x.startswith(("LUT:", "LUT 输入", "Range"))]      # the plan's own notes
+    assert keep(notes_f) == keep(notes_e) and keep(notes_e)
+
+
+def test_engine_command_keeps_the_copy_guard_and_needs_geometry():
+    with pytest.raises(ValueError, match="copy"):
+        engine_command(Path("a"), Path("b"), ProcessingParams(video_codec="copy"), Path("x.cube"), TV10)
+    with pytest.raises(ValueError):
+        engine_command(Path("a"), Path("b"), ProcessingParams(), Path("x.cube"), VideoInfo(pix_fmt="yuv420p"))
+    with pytest.raises(ValueError):
+        engine_command(Path("a"), Path("b"), ProcessingParams(), None, TV10)
+
+
+def test_noise_sweep_distributions():
+    a = frames.make_yuv("noise2", 128, 64, 10, 1, 1, k=0)
+    b = frames.make_yuv("natural", 128, 64, 10, 1, 1, k=0)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))                # sigma 2 IS the natural frame
+    c = frames.make_yuv("noise64", 128, 64, 10, 1, 1, k=0)
+    assert np.abs(c[0].astype(int) - b[0].astype(int)).std() > 20
+    assert c[1].min() >= 64 and c[1].max() <= 960 and c[0].max() <= 940
+    g = frames.make_rgb("noise16", 64, 32, 8, k=1)
+    assert g[0].dtype == np.uint8 and g[0].shape == (32, 64)
+    for bad in ("noise", "noisex", "noise-4", "plasma"):
+        with pytest.raises(ValueError):
+            frames.make_yuv(bad, 16, 16, 8, 1, 1)

@@ -234,3 +234,37 @@ def test_packed_oracle_is_the_pixel_function_through_the_rgba_map(orc, pix_fmt):
             if nc == 4:
                 ao = 6 - ro - go - bo
                 assert out[y, x, ao] == px[ao]
+
+
+def test_near_adds_a_double_half(orc, tmp_path):
+    """vf_lut3d.c: NEAR(x) = (int)(x + .5) with a DOUBLE .5.  At 16 bit, N = 2, DOMAIN_MAX 1.243 the code 40730 lands on
+    s = 0.49999997 (the float just below 1/2): the exact double sum truncates to node 0; a float sum would round up to
+    1.0 and pick node 1.  The oracle, its NumPy twin and (on the GPU box) the kernels must say node 0."""
+    lat = np.zeros((2, 2, 2, 3), dtype=np.float32)
+    lat[1, :, :, 0] = 1.0                                  # red output = index of the red node chosen
+    p = cube.write_cube(tmp_path / "near.cube", lat, domain_min=(0, 0, 0), domain_max=(1.243, 1.243, 1.243))
+    lut = cube.read_cube(p)
+    s = np.float32(np.float32(40730) * np.float32(np.float32(1.0) / np.float32(65535))) * np.float32(lut.scale[0] * np.float32(1))
+    assert s == np.nextafter(np.float32(0.5), np.float32(0))
+    assert orc.apply_pixel(lut.table, lut.scale, 16, "nearest", (40730, 0, 0))[0] == 0
+    assert orc.apply_pixel(lut.table, lut.scale, 16, "nearest", (40731, 0, 0))[0] == 65535
+    got = npo.apply_rgb(lut.table, lut.scale, 16, "nearest", [np.array([[0]], np.uint16), np.array([[0]], np.uint16),
+                                                              np.array([[40730]], np.uint16)])
+    assert int(got[2][0, 0]) == 0
+
+
+def test_domain_scale_subtracts_in_float(orc, tmp_path):
+    """vf_lut3d.c parse_cube: scale = av_clipf(1. / (max - min), 0, 1) with max and min FLOATS, so the subtraction
+    rounds to float before the double division.  DOMAIN 0.3..1.9 tells the two apart: 0.62500006 (float
+    subtraction) vs 0.625 (double subtraction)."""
+    p = tmp_path / "dom.cube"
+    p.write_text("LUT_3D_SIZE 2\nDOMAIN_MIN 0.3 0.2 0.1\nDOMAIN_MAX 1.9 2.3 1.3\n" +
+                 "".join("%d %d %d\n" % (i & 1, (i >> 1) & 1, (i >> 2) & 1) for i in range(8)))
+    want = np.array([np.float32(1.0 / float(np.float32(hi) - np.float32(lo))) for lo, hi in ((0.3, 1.9), (0.2, 2.3), (0.1, 1.3))],
+                    dtype=np.float32)
+    assert want[0] == np.float32(0.62500006) and want[0] != np.float32(0.625)
+    lut = cube.read_cube(p)                               # liblutr's parser
+    n, sc, _ = orc.parse_cube(p)
+    n3, sc3, _ = npo.parse_cube_text(p.read_text())
+    for got in (lut.scale, sc, sc3):
+        assert np.array_equal(np.asarray(got, dtype=np.float32), want), (got, want)
