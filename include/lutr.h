@@ -212,6 +212,16 @@ enum lutr_dither { LUTR_DITHER_NONE = 0, LUTR_DITHER_ERROR_DIFFUSION = 1 };
 int lutr_apply_yuv_dither(lutr_ctx *ctx, const lutr_yuv_params *p, int interp, int dither, int w, int h, int nframes,
                           const lutr_planes *src, const lutr_planes *dst);
 
+/* ---- precision ---- */
+/* STRICT (default): every kernel is a bit-exact restatement of FFmpeg's scalar C lut3d (vf_lut3d.c order of operations,
+ * no fused multiply-add in the blend).  FAST: permission to use the tolerance-bounded tile kernels -- lattice staged as
+ * fp16 of value * (2^depth - 1), blend as a fused multiply-add chain with fp32 accumulation, truncation as in FFmpeg.
+ * Output differs from STRICT by at most ONE code at 8 and at 10 bit (north_star allows 1 / 2 against FFmpeg).  It is
+ * used where it applies (fused YUV launches on the LDS-window kernels, LUT depth 8 or 10, lattice inside [0, 1]);
+ * everything else runs the strict kernels.  lutr_ctx_last_kernel() names what ran (",fast"). */
+enum lutr_precision { LUTR_PRECISION_STRICT = 0, LUTR_PRECISION_FAST = 1 };
+int lutr_ctx_set_precision(lutr_ctx *ctx, int precision);
+
 /* ---- tuning / introspection (bench and tests) ---- */
 /* kernel variant: 0 = auto, 1 = generic (scalar, any layout), 2 = vector + global gather,
  * 3 = vector + LDS lattice window (persistent tile kernels).  Auto picks 3 for launches of 95 Mpx and more
@@ -222,7 +232,8 @@ int lutr_ctx_set_variant(lutr_ctx *ctx, int variant);
 const char *lutr_ctx_last_kernel(lutr_ctx *ctx);
 /* Statistics of the LDS-window tile kernels, accumulated since the previous call.  out[8] (may be
  * NULL) = { tiles, full passes that missed the window, tiles done by the global-gather body, windows
- * staged, shader clock in MHz, longest wave lifetime in us, summed wave lifetimes in us, 0 }.
+ * staged, shader clock in MHz, longest wave lifetime in us, summed wave lifetimes in us, tiles that needed the exact
+ * (second-level) window test }.  The round-2 kernels report no clock / lifetime figures (0).
  * Then collection is enabled (and zeroed) or disabled. */
 int lutr_ctx_tile_stats(lutr_ctx *ctx, int enable, uint64_t out[8]);
 /* the constant block the YUV kernels use, for cross-checking against the oracle: 32 floats */

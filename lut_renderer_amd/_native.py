@@ -20,6 +20,7 @@ MATRIX = {"bt709": 0, "smpte170m": 1, "bt470bg": 1, "bt601": 1, "bt2020nc": 2, "
 RANGE = {"tv": 0, "pc": 1}
 DITHER = {"none": 0, "error_diffusion": 1}
 VARIANT = {"auto": 0, "generic": 1, "vec_global": 2, "vec_lds": 3}
+PRECISION = {"strict": 0, "fast": 1}
 
 #: every symbol include/lutr.h declares (tests check the library exports each one)
 SYMBOLS = (
@@ -29,7 +30,7 @@ SYMBOLS = (
     "lutr_ctx_set_lut", "lutr_ctx_lut_alloc", "lutr_ctx_lut_device", "lutr_ctx_lut_seal",
     "lutr_lattice_bytes", "lutr_lut_broadcast",
     "lutr_apply_planar_rgb", "lutr_apply_packed_rgb", "lutr_apply_yuv", "lutr_apply_yuv_dither",
-    "lutr_ctx_set_variant", "lutr_ctx_last_kernel", "lutr_ctx_tile_stats", "lutr_yuv_constants",
+    "lutr_ctx_set_variant", "lutr_ctx_set_precision", "lutr_ctx_last_kernel", "lutr_ctx_tile_stats", "lutr_yuv_constants",
 )
 
 
@@ -116,6 +117,7 @@ def load() -> C.CDLL:
     lib.lutr_apply_yuv_dither.argtypes = [vp, C.POINTER(YuvParams), ci, ci, ci, ci, ci, C.POINTER(Planes),
                                           C.POINTER(Planes)]
     lib.lutr_ctx_set_variant.argtypes = [vp, ci]
+    lib.lutr_ctx_set_precision.argtypes = [vp, ci]
     lib.lutr_ctx_last_kernel.argtypes = [vp]
     lib.lutr_ctx_last_kernel.restype = cp
     lib.lutr_ctx_tile_stats.argtypes = [vp, ci, C.POINTER(C.c_uint64)]

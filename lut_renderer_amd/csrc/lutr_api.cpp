@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -174,7 +175,17 @@ struct lutr_ctx {
     // that stream wait for it (lutr_ctx_set_stream), so applies issued from different streams serialise on the GPU.
     hipEvent_t done = nullptr;
     bool pending = false;            // `done` was recorded on `stream` and nothing has waited for it yet
+    // fast variant (lutr_ctx_set_precision): fp16 copies of the lattice pre-multiplied by 2^depth - 1, built on first
+    // use per depth (index 0: 8 bit, 1: 10 bit) and dropped whenever the lattice changes
+    int precision = LUTR_PRECISION_STRICT;
+    uint2 *lat16[2] = {nullptr, nullptr};
 };
+
+static void drop_lat16(lutr_ctx *c)
+{
+    for (auto &p : c->lat16)
+        if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); p = nullptr; }
+}
 
 extern "C" {
 
@@ -249,6 +260,7 @@ void lutr_ctx_destroy(lutr_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    drop_lat16(c);
     if (c->lat) (void)hipFree(c->lat);
     if (c->stats) (void)hipFree(c->stats);
     if (c->fscratch) (void)hipFree(c->fscratch);
@@ -280,6 +292,16 @@ int lutr_ctx_sync(lutr_ctx *c)
     return LUTR_OK;
 }
 
+int lutr_ctx_set_precision(lutr_ctx *c, int precision)
+{
+    if (!c || (precision != LUTR_PRECISION_STRICT && precision != LUTR_PRECISION_FAST)) {
+        set_error("bad precision %d", precision);
+        return LUTR_EINVAL;
+    }
+    c->precision = precision;
+    return LUTR_OK;
+}
+
 int lutr_ctx_set_variant(lutr_ctx *c, int variant)
 {
     if (!c || variant < VAR_AUTO || variant > VAR_VEC_LDS) {
@@ -306,6 +328,10 @@ int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[8])
             out[4] = h[5] ? (uint64_t)(100.0 * h[4] / h[5] + 0.5) : 0;          // shader clock, MHz (memtime / 100 MHz realtime)
             out[5] = h[10] / 100;                                                 // longest wave lifetime, us
             out[6] = (uint64_t)h[11] * 64 / 100;                   // summed wave lifetimes, us
+            out[7] = h[6];                                          // tiles that needed the second-level (exact) window test
+            if (getenv("LUTR_DEBUG"))
+                fprintf(stderr, "[lutr stats raw] %u %u %u %u | %u %u %u | %u %u %u | %u %u\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6],
+                        h[7], h[8], h[9], h[10], h[11]);
         }
     }
     if (enable && !c->stats) {
@@ -332,6 +358,7 @@ static int alloc_lattice(lutr_ctx *c, int n, const float scale[3])
             return LUTR_EINVAL;
         }
     HIP_TRY(hipSetDevice(c->device));
+    drop_lat16(c);                   // they describe the previous lattice
     const size_t bytes = lutr_lattice_bytes(n);
     if (bytes != c->lat_bytes) {
         if (c->lat) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->lat); c->lat = nullptr; c->lat_bytes = 0; }
@@ -403,6 +430,7 @@ int lutr_ctx_lut_seal(lutr_ctx *c)
             unit = unit && v[k] >= 0.0f && v[k] <= 1.0f;
         }
     }
+    drop_lat16(c);
     c->unit = unit;
     return LUTR_OK;
 }
@@ -470,10 +498,27 @@ static void fill_planes(PlaneSet *P, const lutr_planes *src, const lutr_planes *
     }
 }
 
-static void fill_lut(LutConsts *L, const lutr_ctx *c, int depth)
+// The fast variant's lattice for `depth`, or nullptr when fast does not apply: strict precision selected, a depth
+// other than 8 / 10 (the tolerance is only defined there), or a lattice outside [0, 1] (the fast kernels are clip-free).
+static const uint2 *fast_lattice(lutr_ctx *c, int depth)
+{
+    if (c->precision != LUTR_PRECISION_FAST || !c->unit || (depth != 8 && depth != 10)) return nullptr;
+    uint2 *&slot = c->lat16[depth == 8 ? 0 : 1];
+    if (!slot) {
+        const size_t nodes = c->lat_bytes / sizeof(float4);
+        void *p = nullptr;
+        if (hipMalloc(&p, nodes * sizeof(uint2)) != hipSuccess) return nullptr;
+        slot = (uint2 *)p;
+        launch_make_lat16(c->stream, c->lat, slot, nodes, (float)((1 << depth) - 1));   // same stream as the apply that follows
+    }
+    return slot;
+}
+
+static void fill_lut(LutConsts *L, lutr_ctx *c, int depth)
 {
     const int maxi = (1 << depth) - 1;
     L->lat = c->lat;
+    L->lat16 = nullptr;
     L->n1 = c->n + 1;
     L->maxf = (float)maxi;
     L->unit = c->unit ? 1 : 0;
@@ -564,9 +609,11 @@ int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int
     HIP_TRY(hipSetDevice(c->device));
     LutConsts L; PlaneSet P; FrameGeom G{w, h, row0, rows, nframes};
     fill_lut(&L, c, p->lut_depth);
+    L.lat16 = fast_lattice(c, p->lut_depth);
     fill_planes(&P, src, dst);
     return finish_launch(c, launch_yuv(c->stream, c->variant, L, K, P, G, LUTR_FMT_DEPTH(p->fmt_in),
-                                       LUTR_FMT_DEPTH(p->fmt_out), csx, csy, interp, c->stats, c->queue));
+                                       LUTR_FMT_DEPTH(p->fmt_out), p->lut_depth, csx, csy, interp, L.lat16 != nullptr,
+                                       c->stats, c->queue));
 }
 
 int lutr_apply_yuv_dither(lutr_ctx *c, const lutr_yuv_params *p, int interp, int dither, int w, int h, int nframes,

@@ -27,6 +27,7 @@ namespace lutr {
 // no clamp in the kernels.
 struct LutConsts {
     const float4 *lat;
+    const uint2  *lat16;  // fast variant: the same nodes as fp16 {r, g, b, 0} of (value * (2^depth - 1)), or nullptr
     int   n1;            // n + 1
     float scale_f;       // 1.0f / (2^depth - 1)
     float sc[3];         // scale.{r,g,b} * (n-1)
@@ -80,8 +81,8 @@ enum Variant { VAR_AUTO = 0, VAR_GENERIC = 1, VAR_VEC_GLOBAL = 2, VAR_VEC_LDS = 
 const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const PlaneSet &P,
                        const FrameGeom &G, int depth, int interp, unsigned *stats, unsigned *queue);
 const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const YuvConsts &K,
-                       const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy,
-                       int interp, unsigned *stats, unsigned *queue);
+                       const PlaneSet &P, const FrameGeom &G, int din, int dout, int lut_depth, int csx, int csy,
+                       int interp, bool fast, unsigned *stats, unsigned *queue);
 
 // packed RGB (lutr_packed.hip)
 const char *launch_packed(hipStream_t st, int variant, const LutConsts &L, const PackedSet &P, const FrameGeom &G,
@@ -90,6 +91,19 @@ const char *launch_packed(hipStream_t st, int variant, const LutConsts &L, const
 // error-diffusion dither path (lutr_dither.hip): whole frames, float planes in F
 const char *launch_yuv_dither(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
                               const FrameGeom &G, const FloatPlanes &F, int din, int dout, int csx, int csy, int interp);
+
+// round-2 tile kernels (lutr_tile2.hip, one translation unit per format: w<in wide><out wide>_c<csx><csy>); nullptr =
+// this combination is not built / cannot take the call, the caller falls back
+#define LUTR_T2_DECL(tag) \
+    const char *launch_yuv_tile2_##tag(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P, \
+                                       const FrameGeom &G, int din, int dout, int lut_depth, int csx, int csy, int mode, \
+                                       bool fast, unsigned *stats, unsigned *queue);
+LUTR_T2_DECL(w00_c11) LUTR_T2_DECL(w00_c10) LUTR_T2_DECL(w00_c00)
+LUTR_T2_DECL(w11_c11) LUTR_T2_DECL(w11_c10) LUTR_T2_DECL(w11_c00)
+LUTR_T2_DECL(w10_c11) LUTR_T2_DECL(w10_c10) LUTR_T2_DECL(w10_c00)
+#undef LUTR_T2_DECL
+// fp16 lattice of the fast variant (lutr_lat16.hip)
+void launch_make_lat16(hipStream_t st, const float4 *lat, uint2 *out, size_t nodes, float m);
 
 // persistent LDS-window kernels (lutr_tile.hip); layout already checked by launch_rgb/launch_yuv
 const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G,

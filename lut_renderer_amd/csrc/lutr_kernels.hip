@@ -116,15 +116,20 @@ __global__ __launch_bounds__(256) void k_rgb_vec(LutConsts L, PlaneSet P, FrameG
     st_words<NW>(P.d[2] + fr * P.dfs[2] + y * P.ds[2] + xo, ro);
 }
 
-template <int WIDE, int CSX, int CSY, int INTERP>
+// WIN / WOUT: 16-bit containers in / out.  A 10-bit source written as 8 bit (the reference's libx264 default,
+// ffmpeg.py:287-302) takes 16 bytes of luma per thread and row so that its 8-bit chroma output is still a whole word.
+template <int WIN, int WOUT> constexpr int vec_bytes() { return (WIN && !WOUT) ? 16 : kVecBytes; }
+
+template <int WIN, int WOUT, int CSX, int CSY, int INTERP>
 __global__ __launch_bounds__(256) void k_yuv_vec(LutConsts L, YuvConsts K, PlaneSet P, FrameGeom G)
 {
-    constexpr int PXT = kVecBytes / (WIDE ? 2 : 1);       // luma samples per thread per row
-    constexpr int YW = kVecBytes / 4;                     // luma words per thread per row
+    constexpr int VB = vec_bytes<WIN, WOUT>();
+    constexpr int PXT = VB / (WIN ? 2 : 1);               // luma samples per thread per row
+    constexpr int YWI = VB / 4, YWO = PXT * (WOUT ? 2 : 1) / 4;   // luma words per thread per row, in / out
     constexpr int BH = 1 << CSY, BW = 1 << CSX;
     constexpr int NC = PXT >> CSX;                        // chroma samples per thread
-    constexpr int CW = NC * (WIDE ? 2 : 1) / 4;           // chroma words per thread (1 or 2)
-    static_assert(CW >= 1, "a thread must own whole chroma words");
+    constexpr int CWI = NC * (WIN ? 2 : 1) / 4, CWO = NC * (WOUT ? 2 : 1) / 4;
+    static_assert(CWI >= 1 && CWO >= 1 && YWO >= 1, "a thread must own whole words");
     const GFetch f(L);
     const unsigned uw = (unsigned)G.w / PXT;
     const unsigned ub = (unsigned)G.rows >> CSY;
@@ -134,52 +139,57 @@ __global__ __launch_bounds__(256) void k_yuv_vec(LutConsts L, YuvConsts K, Plane
     const unsigned xu = u % uw, t = u / uw;
     const int cy = (G.row0 >> CSY) + (int)(t % ub);
     const long long fr = t / ub;
-    const long long xo = (long long)xu * kVecBytes, cxo = (long long)xu * (CW * 4);
+    const long long xi = (long long)xu * VB, xo = (long long)xu * (YWO * 4), cxi = (long long)xu * (CWI * 4), cxo = (long long)xu * (CWO * 4);
 
-    uint32_t yw[BH][YW], cbw[CW], crw[CW];
-    uint32_t yo[BH][YW], cbo[CW], cro[CW];
+    uint32_t yw[BH][YWI], cbw[CWI], crw[CWI];
+    uint32_t yo[BH][YWO], cbo[CWO], cro[CWO];
 #pragma unroll
     for (int dy = 0; dy < BH; dy++) {
-        ld_words<YW>(yw[dy], P.s[0] + fr * P.sfs[0] + (long long)(cy * BH + dy) * P.ss[0] + xo);
+        ld_words<YWI>(yw[dy], P.s[0] + fr * P.sfs[0] + (long long)(cy * BH + dy) * P.ss[0] + xi);
 #pragma unroll
-        for (int k = 0; k < YW; k++) yo[dy][k] = 0;
+        for (int k = 0; k < YWO; k++) yo[dy][k] = 0;
     }
-    ld_words<CW>(cbw, P.s[1] + fr * P.sfs[1] + (long long)cy * P.ss[1] + cxo);
-    ld_words<CW>(crw, P.s[2] + fr * P.sfs[2] + (long long)cy * P.ss[2] + cxo);
+    ld_words<CWI>(cbw, P.s[1] + fr * P.sfs[1] + (long long)cy * P.ss[1] + cxi);
+    ld_words<CWI>(crw, P.s[2] + fr * P.sfs[2] + (long long)cy * P.ss[2] + cxi);
 #pragma unroll
-    for (int k = 0; k < CW; k++) { cbo[k] = 0; cro[k] = 0; }
+    for (int k = 0; k < CWO; k++) { cbo[k] = 0; cro[k] = 0; }
 
 #pragma unroll
     for (int j = 0; j < NC; j++) {
-        const Chroma c = chroma_terms(K, word_sample<WIDE>(cbw, j), word_sample<WIDE>(crw, j));
+        const Chroma c = chroma_terms(K, word_sample<WIN>(cbw, j), word_sample<WIN>(crw, j));
         float rs = 0.f, gs = 0.f, bs = 0.f;
 #pragma unroll
         for (int dy = 0; dy < BH; dy++) {
 #pragma unroll
             for (int dx = 0; dx < BW; dx++) {
                 const int i = j * BW + dx;
-                const Rgb q = yuv_to_rgb(K, word_sample<WIDE>(yw[dy], i), c);
+                const Rgb q = yuv_to_rgb(K, word_sample<WIN>(yw[dy], i), c);
                 const Rgb o = lut3d_px<INTERP>(L, f, q.r, q.g, q.b);
                 rs += o.r; gs += o.g; bs += o.b;
-                word_put<WIDE>(yo[dy], i, rgb_to_y(K, o));
+                word_put<WOUT>(yo[dy], i, rgb_to_y(K, o));
             }
         }
-        word_put<WIDE>(cbo, j, rgb_to_cb(K, rs, gs, bs));
-        word_put<WIDE>(cro, j, rgb_to_cr(K, rs, gs, bs));
+        word_put<WOUT>(cbo, j, rgb_to_cb(K, rs, gs, bs));
+        word_put<WOUT>(cro, j, rgb_to_cr(K, rs, gs, bs));
         // Zero-instruction fence: without it hipcc hoists the coordinates and taps of every chroma block of the
         // thread to the top (256 VGPRs, one wave per SIMD); with it blocks are emitted one after the other.
 #pragma unroll
-        for (int dy = 0; dy < BH; dy++)
+        for (int dy = 0; dy < BH; dy++) {
 #pragma unroll
-            for (int k = 0; k < YW; k++) asm volatile("" : "+v"(yw[dy][k]), "+v"(yo[dy][k]));
+            for (int k = 0; k < YWI; k++) asm volatile("" : "+v"(yw[dy][k]));
 #pragma unroll
-        for (int k = 0; k < CW; k++) asm volatile("" : "+v"(cbw[k]), "+v"(crw[k]), "+v"(cbo[k]), "+v"(cro[k]));
+            for (int k = 0; k < YWO; k++) asm volatile("" : "+v"(yo[dy][k]));
+        }
+#pragma unroll
+        for (int k = 0; k < CWI; k++) asm volatile("" : "+v"(cbw[k]), "+v"(crw[k]));
+#pragma unroll
+        for (int k = 0; k < CWO; k++) asm volatile("" : "+v"(cbo[k]), "+v"(cro[k]));
     }
 #pragma unroll
     for (int dy = 0; dy < BH; dy++)
-        st_words<YW>(P.d[0] + fr * P.dfs[0] + (long long)(cy * BH + dy) * P.ds[0] + xo, yo[dy]);
-    st_words<CW>(P.d[1] + fr * P.dfs[1] + (long long)cy * P.ds[1] + cxo, cbo);
-    st_words<CW>(P.d[2] + fr * P.dfs[2] + (long long)cy * P.ds[2] + cxo, cro);
+        st_words<YWO>(P.d[0] + fr * P.dfs[0] + (long long)(cy * BH + dy) * P.ds[0] + xo, yo[dy]);
+    st_words<CWO>(P.d[1] + fr * P.dfs[1] + (long long)cy * P.ds[1] + cxo, cbo);
+    st_words<CWO>(P.d[2] + fr * P.dfs[2] + (long long)cy * P.ds[2] + cxo, cro);
 }
 
 // ================================================================= launchers
@@ -268,13 +278,55 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     return nullptr;
 }
 
+// Round-2 tile kernels (lutr_tile2.hip): input and output depth are independent there, so source planes are checked
+// against the input unit (16 bytes of luma, the matching chroma bytes) and destination planes against the output unit.
+static bool plane_ok(const uint8_t *p, long long stride, long long fstride, long long a, bool batch)
+{
+    constexpr long long kMaxStride = (0xffffffffll - 64 * 32) / 32;
+    return stride > 0 && stride <= kMaxStride && aligned_to(p, a) && stride % a == 0 && (!batch || (fstride >= 0 && fstride % a == 0));
+}
+
+static const char *try_tile2(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P, const FrameGeom &G,
+                             int din, int dout, int lut_depth, int csx, int csy, int mode, bool fast, unsigned *stats, unsigned *queue)
+{
+    if (getenv("LUTR_NO_TILE2")) return nullptr;
+    const int win = din > 8, wout = dout > 8, pxt = win ? 8 : 16, bh = 1 << csy;
+    if (!(mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL)) return nullptr;
+    if (G.w % pxt || G.row0 % bh || G.rows % bh || (csx == 0 && csy == 1)) return nullptr;
+    if ((long long)(G.w / pxt) * (G.rows >> csy) * G.nframes >= 0x7fffffffll) return nullptr;
+    const long long yi = 16, yo = (long long)pxt * (wout ? 2 : 1), ci = (long long)(pxt >> csx) * (win ? 2 : 1),
+                    co = (long long)(pxt >> csx) * (wout ? 2 : 1);
+    const bool batch = G.nframes > 1;
+    if (!plane_ok(P.s[0], P.ss[0], P.sfs[0], yi, batch) || !plane_ok(P.d[0], P.ds[0], P.dfs[0], yo > 16 ? 16 : yo, batch)) return nullptr;
+    for (int c = 1; c < 3; c++)
+        if (!plane_ok(P.s[c], P.ss[c], P.sfs[c], ci, batch) || !plane_ok(P.d[c], P.ds[c], P.dfs[c], co, batch)) return nullptr;
+#define T2_TRY(tag) return launch_yuv_tile2_##tag(st, L, K, P, G, din, dout, lut_depth, csx, csy, mode, fast, stats, queue)
+    const int key = win * 1000 + wout * 100 + csx * 10 + csy;
+    switch (key) {
+    case 11:   T2_TRY(w00_c11);
+    case 10:   T2_TRY(w00_c10);
+    case 0:    T2_TRY(w00_c00);
+    case 1111: T2_TRY(w11_c11);
+    case 1110: T2_TRY(w11_c10);
+    case 1100: T2_TRY(w11_c00);
+    case 1011: T2_TRY(w10_c11);
+    case 1010: T2_TRY(w10_c10);
+    case 1000: T2_TRY(w10_c00);
+    }
+#undef T2_TRY
+    return nullptr;
+}
+
 const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const YuvConsts &K,
-                       const PlaneSet &P, const FrameGeom &G, int din, int dout, int csx, int csy, int mode,
-                       unsigned *stats, unsigned *queue)
+                       const PlaneSet &P, const FrameGeom &G, int din, int dout, int lut_depth, int csx, int csy, int mode,
+                       bool fast, unsigned *stats, unsigned *queue)
 {
     const int win = din > 8, wout = dout > 8;
     const int pxt = win ? 8 : 16;
     const int bh = 1 << csy;
+    if (variant == VAR_VEC_LDS || (variant == VAR_AUTO && !small_job((long long)G.w * G.rows * G.nframes))) {
+        if (const char *name = try_tile2(st, L, K, P, G, din, dout, lut_depth, csx, csy, mode, fast, stats, queue)) return name;
+    }
     const long long cbytes = (long long)(pxt >> csx) * (win ? 2 : 1);      // chroma bytes per thread
     bool vec_ok = (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
                   win == wout && G.w % pxt == 0 && G.row0 % bh == 0 && G.rows % bh == 0 &&
@@ -307,6 +359,25 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
                            csx, csy, mode);
         return name;
     }
+    // 10-bit (or deeper) source written as 8 bit: the vector kernel with 16-byte luma units
+    if (!vec_ok && variant != VAR_GENERIC && win == 1 && wout == 0 &&
+        (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
+        G.w % 8 == 0 && G.row0 % bh == 0 && G.rows % bh == 0 && !(csx == 0 && csy == 1) &&
+        (long long)(G.w / 8) * (G.rows >> csy) * G.nframes < 0x7fffffffll &&
+        plane_ok(P.s[0], P.ss[0], P.sfs[0], 16, G.nframes > 1) && plane_ok(P.d[0], P.ds[0], P.dfs[0], 8, G.nframes > 1) &&
+        plane_ok(P.s[1], P.ss[1], P.sfs[1], 16 >> csx, G.nframes > 1) && plane_ok(P.d[1], P.ds[1], P.dfs[1], 8 >> csx, G.nframes > 1) &&
+        plane_ok(P.s[2], P.ss[2], P.sfs[2], 16 >> csx, G.nframes > 1) && plane_ok(P.d[2], P.ds[2], P.dfs[2], 8 >> csx, G.nframes > 1)) {
+        const dim3 grid(grid_for((long long)(G.w / 8) * (G.rows >> csy) * G.nframes)), block(256);
+#define YUV10_CASE(X, Y, I) \
+        if (csx == X && csy == Y && mode == I) { \
+            hipLaunchKernelGGL((k_yuv_vec<1, 0, X, Y, I>), grid, block, 0, st, L, K, P, G); \
+            return "k_yuv_vec<10," #X "," #Y "," #I ">"; \
+        }
+#define YUV10_FMT(X, Y) YUV10_CASE(X, Y, 0) YUV10_CASE(X, Y, 1) YUV10_CASE(X, Y, 2)
+        YUV10_FMT(1, 1) YUV10_FMT(1, 0) YUV10_FMT(0, 0)
+#undef YUV10_FMT
+#undef YUV10_CASE
+    }
     if (!vec_ok) {
         if (variant == VAR_VEC_GLOBAL || variant == VAR_VEC_LDS) return nullptr;
         const long long blocks = (long long)((G.w + (1 << csx) - 1) >> csx) * ((G.rows + bh - 1) >> csy) * G.nframes;
@@ -318,7 +389,7 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     const dim3 grid(grid_for(units)), block(256);
 #define YUV_CASE(W, X, Y, I) \
     if (win == W && csx == X && csy == Y && mode == I) { \
-        hipLaunchKernelGGL((k_yuv_vec<W, X, Y, I>), grid, block, 0, st, L, K, P, G); \
+        hipLaunchKernelGGL((k_yuv_vec<W, W, X, Y, I>), grid, block, 0, st, L, K, P, G); \
         return "k_yuv_vec<" #W "," #X "," #Y "," #I ">"; \
     }
 #define YUV_FMT(W, X, Y) YUV_CASE(W, X, Y, 0) YUV_CASE(W, X, Y, 1) YUV_CASE(W, X, Y, 2)

@@ -1,0 +1,1191 @@
+// lutr_tile2.hip -- round-2 fused YUV tile kernels: persistent waves, per-wave LDS lattice window, and a window
+// whose validity is decided in RAW CODE SPACE before any pixel is computed.
+//
+// Replaces the slice-threaded per-row loops of FFmpeg's lut3d + the scalers around it
+// (the filters /root/reference/src/lut_renderer/ffmpeg.py:212-247,:304-310 emits).
+//
+// What changed against round 1's lutr_tile.hip (DESIGN.md "Kernels" has the measurements):
+//   * VALIDITY WITHOUT PER-PIXEL WORK.  Round 1 computed a tile optimistically, accumulated min/max of every
+//     pixel's lattice cell (6 VALU per pixel), voted, and redid the tile on a miss.  Here a window carries a BOX
+//     [y]x[cb]x[cr] of raw input codes with the guarantee that every pixel inside the box only touches staged
+//     nodes.  A tile's raw extremes come from v_pk_min/max_u16 on the packed input words (~1.7 VALU per pixel),
+//     one saturating-subtract test per plane says whether the lane's unit is inside the box, one vote per tile.
+//     No tile is ever computed twice, no address clamp is needed, and the body has no bounds code at all.
+//     box -> cells is a conservative map (map_box below) that exploits what the sheared window exploits: in
+//     (r, g-r, b-r) coordinates luma cancels out of the two chroma-like axes.
+//   * PADDED PER-CODE TABLE.  The {prev, frac} table covers every index the YUV->RGB sum can reach (negative sums
+//     saturate to 0 in v_cvt_u32_f32), so the per-channel v_min_u32 is gone.
+//   * OUTPUT PACKING BY SDWA.  v_cvt_u32_f32_sdwa writes a sample straight into its half-word / byte.
+//   * FAST VARIANT (V = 3).  LDS nodes are 8-byte {r,g,b,-} fp16 pre-multiplied by 2^depth-1; the blend is an fma chain
+//     of v_fma_mix_f32 (fp16 tap x fp32 weight + fp32 accumulator, exact products, one rounding per step): 12 VALU
+//     instead of 24 per pixel, a tap is one ds_read_b64, the window holds 2-3x the nodes.  (Measured alternative: fp32
+//     float4 nodes pre-multiplied by M with plain v_fma_f32 -- full-rate VALU, but ds_read_b128 taps run into LDS bank
+//     conflicts: 403 vs 560 Gpx/s.)  |fast - strict| <= 1 code at 8 and 10 bit (tests/test_fast_variant.py, DESIGN.md
+//     3.4); the strict kernels stay bit-identical to the oracle.
+//   * Input and output depth are independent (10-bit in, 8-bit out is the reference's libx264 default).
+//
+// Arithmetic of the strict variants: -ffp-contract=off, FFmpeg's scalar C order, bit-identical to the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <set>
+#include <type_traits>
+#include <utility>
+
+#include "lutr_internal.h"
+
+// One translation unit per (input width, output width, chroma layout): the Makefile compiles this file nine times
+// (-DLUTR_T2_WI=.. -DLUTR_T2_WO=.. -DLUTR_T2_X=.. -DLUTR_T2_Y=..), in parallel, each defining launch_yuv_tile2_w<WI><WO>_c<X><Y>.
+#ifndef LUTR_T2_WI
+#define LUTR_T2_WI 1
+#define LUTR_T2_WO 1
+#define LUTR_T2_X 1
+#define LUTR_T2_Y 1
+#endif
+#define T2_CAT_(a, b, c, d) launch_yuv_tile2_w##a##b##_c##c##d
+#define T2_CAT(a, b, c, d) T2_CAT_(a, b, c, d)
+#define T2_ENTRY T2_CAT(LUTR_T2_WI, LUTR_T2_WO, LUTR_T2_X, LUTR_T2_Y)
+
+#ifndef LUTR_T2_WPB
+#define LUTR_T2_WPB 16            // waves per workgroup: one workgroup per CU shares one coordinate table
+#endif
+#ifndef LUTR_T2_WAVES_PER_EU
+#define LUTR_T2_WAVES_PER_EU 4
+#endif
+#ifndef LUTR_T2_PHASES
+#define LUTR_T2_PHASES 1          // scheduling barriers between the load and use phases of a pixel group (tile_body)
+#endif
+
+namespace lutr {
+namespace t2 {
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+enum { V_GEN = 0, V_TAB = 1, V_UNIT = 2, V_FAST = 3 };
+
+#define DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- small machine helpers
+DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DEV float med3(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
+DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+DEV float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+DEV float in_vgpr(float s)
+{
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+DEV uint32_t pk_min(uint32_t a, uint32_t b) { uint32_t o; asm("v_pk_min_u16 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
+DEV uint32_t pk_max(uint32_t a, uint32_t b) { uint32_t o; asm("v_pk_max_u16 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
+// per 16-bit half: max(a - b, 0)
+DEV uint32_t pk_subsat_sv(uint32_t a, uint32_t b) { uint32_t o; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(o) : "s"(a), "v"(b)); return o; }
+DEV uint32_t pk_subsat_vs(uint32_t a, uint32_t b) { uint32_t o; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(o) : "v"(a), "s"(b)); return o; }
+
+// fp32 weight x fp16 tap (+ fp32 accumulator): v_fma_mix_f32, products exact, one rounding (== fmaf(w, (float)h, c))
+DEV float mix0_lo(float w, uint32_t h) { float d; asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(h)); return d; }
+DEV float mix0_hi(float w, uint32_t h) { float d; asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(h)); return d; }
+DEV float mix_lo(float w, uint32_t h, float c) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(h), "v"(c)); return d; }
+DEV float mix_hi(float w, uint32_t h, float c) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(h), "v"(c)); return d; }
+// fp16 - fp16 -> fp32 (one rounding), and f * t + fp16: the two halves of a lerp whose end points are fp16 taps
+DEV float hsub_lo(uint32_t a, uint32_t b) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+DEV float hsub_hi(uint32_t a, uint32_t b) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+DEV float hlerp_lo(float t, float f, uint32_t v0) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(t), "v"(f), "v"(v0)); return d; }
+DEV float hlerp_hi(float t, float f, uint32_t v0) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(t), "v"(f), "v"(v0)); return d; }
+
+DEV int lds_base() { return (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem; }
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------- geometry shared with the launcher
+struct Geom {
+    int lw_log2;          // lanes along x per tile row = 1 << lw_log2 (the other lanes go down)
+    int uw, urows;        // units per row, unit rows (a unit = PXT px x BH rows)
+    int nsx, nry;         // tiles across, tiles down
+    int ch, nrc, nchunks; // chunk = `ch` consecutive tile rows of one strip; chunk id = (frame*nrc + rc)*nsx + strip
+    int win_nodes;        // LDS window capacity per wave, in nodes
+    int tab_entries;      // per-code coordinate table at LDS offset 0 (0 = coordinates are computed)
+    int max_raw;          // 2^din - 1: a raw code above it cannot be trusted to stay inside the table
+    unsigned *queue;      // device counter, set by the launcher before every launch
+    unsigned *stats;      // optional device counters; nullptr = off
+};
+
+struct Planes2 {          // 32-bit strides: the launcher only sends layouts that fit (planes_aligned)
+    const uint8_t *s[3];
+    uint8_t       *d[3];
+    unsigned ss[3], ds[3];
+    unsigned long long sfs[3], dfs[3];
+};
+
+// ---------------------------------------------------------------- variant traits
+template <int INTERP, int V> struct Node {
+    static constexpr bool fast = V == V_FAST;
+    // bytes per node in a window: fast = four fp16 {r,g,b,-} (one ds_read_b64 per tap); strict 4-tap modes pack fp32 {r,g,b}
+    // (a third more nodes per wave than float4; a tap is ds_read2_b32 + ds_read_b32); strict trilinear reads float4 nodes
+    static constexpr int lds = fast ? 8 : (INTERP == LUTR_INTERP_TRILINEAR ? 16 : 12);
+    static constexpr int glb = fast ? 8 : 16;                                              // bytes per node in HBM/L2
+};
+
+// ---------------------------------------------------------------- window (wave-uniform)
+struct Win {
+    float fr, fg, fb, fc;        // LDS byte address of the c000 tap: (int) fma(pr, fr, fma(pg, fg, fma(pb, fb, fc)))
+    int   o_r, o_g;              // byte steps of +1 along r and g (blue is one node)
+    // raw-code box this window is good for, each bound replicated in both 16-bit halves (8-bit planes: code << 8,
+    // upper bounds | 0xff -- see extremes())
+    uint32_t ylo, yhi, cblo, cbhi, crlo, crhi;
+};
+
+struct Ext { uint32_t ymin, ymax, cbmin, cbmax, crmin, crmax; };   // packed per-lane extremes of a unit
+
+// (prev, frac) of one channel
+struct Crd { float p, d; };
+
+template <int INTERP>
+DEV Crd crd_compute(const LutConsts &L, float code, float sc)
+{
+    const float x = code * L.scale_f;
+    const float s = fminf(x * sc, L.lut_max);       // codes and scales are >= 0: only the upper clip can bind
+    Crd c;
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) {  // NEAR(x) = (int)(x + .5) with a double .5 (lutr_device.h near_f)
+        const float fl = floorf(s);
+        c.p = (s - fl >= .5f) ? fl + 1.0f : fl;
+        c.d = 0.0f;
+    } else { c.p = floorf(s); c.d = s - c.p; }
+    return c;
+}
+
+DEV Crd crd_table(unsigned idx)
+{
+    const float2 e = *(const float2 *)(smem + idx * 8u);
+    return Crd{e.x, e.y};
+}
+
+// Entry i of the table = coordinates of code min(i, M): indices past M are what an out-of-gamut YUV triple produces
+// before FFmpeg's clip to the depth; the clip is folded into the table.
+template <int INTERP>
+DEV void coord_table_fill(const LutConsts &L, int entries)
+{
+    for (int q = threadIdx.x; q < entries; q += 64 * LUTR_T2_WPB) {
+        const Crd c = crd_compute<INTERP>(L, fminf((float)q, L.maxf), L.sc[0]);
+        *(float2 *)(smem + q * 8) = make_float2(c.p, c.d);
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- tiles
+template <int WIN, int WOUT, int CSX, int CSY>
+struct Tile {
+    static constexpr int PXT = WIN ? 8 : 16;                         // luma samples per unit row (16 bytes in)
+    static constexpr int BH = 1 << CSY, BW = 1 << CSX;
+    static constexpr int NC = PXT >> CSX;                            // chroma samples per unit
+    static constexpr int YWI = 4, YWO = PXT * (WOUT ? 2 : 1) / 4;    // luma words per row, in / out
+    static constexpr int CWI = NC * (WIN ? 2 : 1) / 4, CWO = NC * (WOUT ? 2 : 1) / 4;
+    static_assert(CWI >= 1 && CWO >= 1, "a unit must own whole chroma words");
+};
+template <int WIN, int WOUT, int CSX, int CSY> struct TileIn { using T = Tile<WIN, WOUT, CSX, CSY>; uint32_t y[T::BH][T::YWI], cb[T::CWI], cr[T::CWI]; };
+template <int WIN, int WOUT, int CSX, int CSY> struct TileOut { using T = Tile<WIN, WOUT, CSX, CSY>; uint32_t y[T::BH][T::YWO], cb[T::CWO], cr[T::CWO]; };
+
+template <int WIDE>
+DEV float wsample(const uint32_t *w, int i)
+{
+    if constexpr (WIDE) return (float)((w[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+    else return (float)((w[i >> 2] >> ((i & 3) * 8)) & 0xffu);
+}
+
+// floor(v) for v >= 0 (negatives saturate to 0) written into sample i of the word vector: one SDWA conversion
+// (v_cvt_u32_f32 truncates) instead of convert + shift-or.
+template <int WIDE>
+DEV void wput(uint32_t *w, int i, float v)
+{
+    if constexpr (WIDE) {
+        if ((i & 1) == 0) w[i >> 1] = (uint32_t)v;
+        else asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w[i >> 1]) : "v"(v));
+    } else {
+        uint32_t &d = w[i >> 2];
+        switch (i & 3) {
+        case 0: d = (uint32_t)v; break;
+        case 1: asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(v)); break;
+        case 2: asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(v)); break;
+        default: asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(v)); break;
+        }
+    }
+}
+
+template <int NW> DEV void ldw(uint32_t *w, const uint8_t *p)
+{
+    if constexpr (NW == 4) { const uint4 v = *(const uint4 *)p; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else if constexpr (NW == 2) { const uint2 v = *(const uint2 *)p; w[0] = v.x; w[1] = v.y; }
+    else w[0] = *(const uint32_t *)p;
+}
+template <int NW> DEV void stw(uint8_t *p, const uint32_t *w)
+{
+    if constexpr (NW == 8) { *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]); *(uint4 *)(p + 16) = make_uint4(w[4], w[5], w[6], w[7]); }
+    else if constexpr (NW == 4) *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]);
+    else if constexpr (NW == 2) *(uint2 *)p = make_uint2(w[0], w[1]);
+    else *(uint32_t *)p = w[0];
+}
+
+template <int N> DEV void fence_words(uint32_t *w)
+{
+    if constexpr (N == 1) asm volatile("" : "+v"(w[0]));
+    else if constexpr (N == 2) asm volatile("" : "+v"(w[0]), "+v"(w[1]));
+    else if constexpr (N == 4) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    else if constexpr (N == 8) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+    else if constexpr (N == 16) { fence_words<8>(w); fence_words<8>(w + 8); }
+}
+
+// ---------------------------------------------------------------- raw extremes of a unit
+// 16-bit containers: the words ARE pairs of samples.  8-bit: a word and the word shifted left by 8 are two streams of
+// u16 whose HIGH byte is a sample (the low byte only breaks ties), so the same packed min/max yields exact byte
+// extremes in the high bytes; bounds are compared as (code << 8) and (code << 8 | 0xff).
+template <int WIN, int N>
+DEV void ext_words(const uint32_t *w, uint32_t &mn, uint32_t &mx, bool first)
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (first && k == 0) { mn = mx = w[0]; }
+        else { mn = pk_min(mn, w[k]); mx = pk_max(mx, w[k]); }
+        if constexpr (!WIN) { const uint32_t t = w[k] << 8; mn = pk_min(mn, t); mx = pk_max(mx, t); }
+    }
+}
+
+template <int WIN, int WOUT, int CSX, int CSY>
+DEV Ext extremes(const TileIn<WIN, WOUT, CSX, CSY> &in)
+{
+    using T = Tile<WIN, WOUT, CSX, CSY>;
+    Ext e;
+#pragma unroll
+    for (int dy = 0; dy < T::BH; dy++) ext_words<WIN, T::YWI>(in.y[dy], e.ymin, e.ymax, dy == 0);
+    ext_words<WIN, T::CWI>(in.cb, e.cbmin, e.cbmax, true);
+    ext_words<WIN, T::CWI>(in.cr, e.crmin, e.crmax, true);
+    return e;
+}
+
+DEV bool box_holds(const Win &W, const Ext &e)
+{
+    // every half >= lo and <= hi  <=>  all six saturating differences are zero
+    const uint32_t a = pk_subsat_sv(W.ylo, e.ymin) | pk_subsat_vs(e.ymax, W.yhi) | pk_subsat_sv(W.cblo, e.cbmin);
+    const uint32_t b = pk_subsat_vs(e.cbmax, W.cbhi) | pk_subsat_sv(W.crlo, e.crmin) | pk_subsat_vs(e.crmax, W.crhi);
+    return __all((a | b) == 0u);
+}
+
+// ---------------------------------------------------------------- box -> cells (conservative, wave-uniform)
+// Raw box (float codes, inclusive) -> inclusive ranges of the sheared cell coordinates (pr, pg-pr, pb-pr) that any
+// pixel inside the box can produce.  Every float op of the pixel pipeline is monotone in its inputs, so per-channel
+// cell ranges follow exactly from evaluating the SAME ops at the right corners.  For the two difference axes that would
+// throw away the one thing that makes the sheared window small (luma cancels), so they are bounded analytically:
+//   pg - pr in (sg - sr - 1, sg - sr + 1),  sg - sr = kappa (qG - qR) +- 2 delta_s,
+//   qG - qR in (dG - 1 - eps, dG + 1 + eps) with dG = gv - rv a function of chroma only (monotone in cb and in cr),
+// and where FFmpeg's clip to [0, M] can bind inside the box the clipped difference lies between 0 and the unclipped one.
+// The result is intersected with plain interval arithmetic on the per-channel ranges (also valid).
+struct Cells { int r0, r1, g0, g1, b0, b1; };
+
+template <int INTERP, int PRE, int V>
+DEV float cell_of(const LutConsts &L, float q, int ch, int tab_entries)
+{
+    if constexpr (V >= V_TAB) { (void)ch; (void)tab_entries; return crd_table((unsigned)q).p; }
+    else { (void)tab_entries; return crd_compute<INTERP>(L, q, L.sc[ch]).p; }
+}
+
+DEV float qclip(float v, float m) { return med3(floorf(v), 0.0f, m); }
+DEV float cfloor(float v, float hi) { return med3(floorf(v), 0.0f, hi); }
+
+template <int INTERP, int PRE, int V>
+DEV Cells map_box(const LutConsts &L, const YuvConsts &K, const Geom &TG, float y0, float y1, float cb0, float cb1, float cr0, float cr1)
+{
+    if constexpr (PRE) {       // the range/depth prologue is a monotone map of each plane
+        y0 = qclip(fma_(K.py, y0, K.pyb), K.pre_max); y1 = qclip(fma_(K.py, y1, K.pyb), K.pre_max);
+        cb0 = qclip(fma_(K.pc, cb0, K.pcb), K.pre_max); cb1 = qclip(fma_(K.pc, cb1, K.pcb), K.pre_max);
+        cr0 = qclip(fma_(K.pc, cr0, K.pcb), K.pre_max); cr1 = qclip(fma_(K.pc, cr1, K.pcb), K.pre_max);
+    }
+    const float yy0 = fma_(K.ky, y0, K.yb), yy1 = fma_(K.ky, y1, K.yb);
+    const float cbd0 = cb0 - K.coff, cbd1 = cb1 - K.coff, crd0 = cr0 - K.coff, crd1 = cr1 - K.coff;
+    // krv, kbu > 0; kgu, kgv < 0 for every matrix (make_yuv_consts)
+    const float rv0 = K.krv * crd0, rv1 = K.krv * crd1, bu0 = K.kbu * cbd0, bu1 = K.kbu * cbd1;
+    const float gv0 = fma_(K.kgu, cbd1, K.kgv * crd1), gv1 = fma_(K.kgu, cbd0, K.kgv * crd0);      // min, max
+    const float m = K.max_l;
+    const float vr0 = yy0 + rv0, vr1 = yy1 + rv1, vg0 = yy0 + gv0, vg1 = yy1 + gv1, vb0 = yy0 + bu0, vb1 = yy1 + bu1;
+    const int te = TG.tab_entries;
+    const float pr0 = cell_of<INTERP, PRE, V>(L, qclip(vr0, m), 0, te), pr1 = cell_of<INTERP, PRE, V>(L, qclip(vr1, m), 0, te);
+    const float pg0 = cell_of<INTERP, PRE, V>(L, qclip(vg0, m), 1, te), pg1 = cell_of<INTERP, PRE, V>(L, qclip(vg1, m), 1, te);
+    const float pb0 = cell_of<INTERP, PRE, V>(L, qclip(vb0, m), 2, te), pb1 = cell_of<INTERP, PRE, V>(L, qclip(vb1, m), 2, te);
+    Cells c;
+    c.r0 = (int)pr0; c.r1 = (int)pr1;
+    float g_lo = pg0 - pr1, g_hi = pg1 - pr0, b_lo = pb0 - pr1, b_hi = pb1 - pr0;               // interval arithmetic
+    if (L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2]) {
+        // chroma-only difference terms at the corners that extremise them: gv - rv falls in cb and in cr;
+        // bu - rv rises in cb and falls in cr
+        float dg0 = gv0 - rv1, dg1 = gv1 - rv0;
+        float db0 = bu0 - rv1, db1 = bu1 - rv0;
+        const bool clips = vr0 < 0.0f || vg0 < 0.0f || vb0 < 0.0f || vr1 >= m + 1.0f || vg1 >= m + 1.0f || vb1 >= m + 1.0f;
+        if (clips) { dg0 = fminf(dg0, 0.0f); dg1 = fmaxf(dg1, 0.0f); db0 = fminf(db0, 0.0f); db1 = fmaxf(db1, 0.0f); }
+        const float kappa = L.sc[0] * L.scale_f;
+        const float eps = m * (1.0f / 2097152.0f) + 1e-3f;                    // float rounding of the sums, and then some
+        const float slack = 1.0f + 2.0f * L.lut_max * (1.0f / 2097152.0f) + 2e-3f;
+        g_lo = fmaxf(g_lo, floorf(kappa * (dg0 - 1.0f - eps) - slack) + 1.0f);
+        g_hi = fminf(g_hi, ceilf(kappa * (dg1 + 1.0f + eps) + slack) - 1.0f);
+        b_lo = fmaxf(b_lo, floorf(kappa * (db0 - 1.0f - eps) - slack) + 1.0f);
+        b_hi = fminf(b_hi, ceilf(kappa * (db1 + 1.0f + eps) + slack) - 1.0f);
+    }
+    c.g0 = (int)g_lo; c.g1 = (int)g_hi; c.b0 = (int)b_lo; c.b1 = (int)b_hi;
+    return c;
+}
+
+// ---------------------------------------------------------------- exact cell bounds of a tile (second-level test)
+// When the raw-box test fails the tile is not necessarily outside the window: the box is a conservative, axis-aligned
+// description (uncorrelated sensor noise in Cb and Cr spans a box whose corners no pixel reaches).  The second level
+// computes what round 1 computed for every tile: the exact cells each pixel touches, min/max per lane, one vote against
+// the window's cell ranges.  ~18 VALU per pixel, paid only by the tiles that fail the cheap test.
+struct Bnd { float rmin, rmax, gmin, gmax, bmin, bmax; };
+
+DEV float vmin3(float a, float b, float c) { float o; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c)); return o; }
+DEV float vmax3(float a, float b, float c) { float o; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c)); return o; }
+
+template <int WIN, int WOUT, int CSX, int CSY, int INTERP, int PRE, int V>
+DEV Bnd tile_bounds(const LutConsts &L, const YuvConsts &K, const Geom &TG, TileIn<WIN, WOUT, CSX, CSY> &in)
+{
+    using T = Tile<WIN, WOUT, CSX, CSY>;
+    Bnd bn;
+    bn.rmin = bn.gmin = bn.bmin = 1e9f;
+    bn.rmax = bn.gmax = bn.bmax = -1e9f;
+#pragma unroll
+    for (int j = 0; j < T::NC; j++) {
+        float cbv = wsample<WIN>(in.cb, j), crv = wsample<WIN>(in.cr, j);
+        if constexpr (PRE) {
+            cbv = cfloor(fma_(K.pc, cbv, K.pcb), K.pre_max);
+            crv = cfloor(fma_(K.pc, crv, K.pcb), K.pre_max);
+        }
+        const float cbd = cbv - K.coff, crd = crv - K.coff;
+        const float rv = K.krv * crd, gv = fma_(K.kgu, cbd, K.kgv * crd), bu = K.kbu * cbd;
+        constexpr int NQ = T::BH * T::BW;
+        float pr[NQ], pg_[NQ], pb_[NQ], hg[NQ], hb[NQ];
+        // all table reads of the chroma block first, then their uses (one LDS round trip per block, not per pixel)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int dy = q / T::BW, dx = q % T::BW;
+            float yv = wsample<WIN>(in.y[dy], j * T::BW + dx);
+            if constexpr (PRE) yv = cfloor(fma_(K.py, yv, K.pyb), K.pre_max);
+            const float yy = fma_(K.ky, yv, K.yb);
+            if constexpr (V >= V_TAB) {
+                const unsigned top = (unsigned)(TG.tab_entries - 1);          // raw codes are unvetted here
+                pr[q] = *(const float *)(smem + min((unsigned)(yy + rv), top) * 8u);
+                pg_[q] = *(const float *)(smem + min((unsigned)(yy + gv), top) * 8u);
+                pb_[q] = *(const float *)(smem + min((unsigned)(yy + bu), top) * 8u);
+            } else {
+                pr[q] = crd_compute<INTERP>(L, cfloor(yy + rv, K.max_l), L.sc[0]).p;
+                pg_[q] = crd_compute<INTERP>(L, cfloor(yy + gv, K.max_l), L.sc[1]).p;
+                pb_[q] = crd_compute<INTERP>(L, cfloor(yy + bu, K.max_l), L.sc[2]).p;
+            }
+        }
+#if LUTR_T2_PHASES
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { hg[q] = pg_[q] - pr[q]; hb[q] = pb_[q] - pr[q]; }
+        if constexpr (T::BH * T::BW >= 2) {
+#pragma unroll
+            for (int q = 0; q + 1 < T::BH * T::BW; q += 2) {
+                bn.rmin = vmin3(bn.rmin, pr[q], pr[q + 1]); bn.rmax = vmax3(bn.rmax, pr[q], pr[q + 1]);
+                bn.gmin = vmin3(bn.gmin, hg[q], hg[q + 1]); bn.gmax = vmax3(bn.gmax, hg[q], hg[q + 1]);
+                bn.bmin = vmin3(bn.bmin, hb[q], hb[q + 1]); bn.bmax = vmax3(bn.bmax, hb[q], hb[q + 1]);
+            }
+        } else {
+            bn.rmin = fminf(bn.rmin, pr[0]); bn.rmax = fmaxf(bn.rmax, pr[0]);
+            bn.gmin = fminf(bn.gmin, hg[0]); bn.gmax = fmaxf(bn.gmax, hg[0]);
+            bn.bmin = fminf(bn.bmin, hb[0]); bn.bmax = fmaxf(bn.bmax, hb[0]);
+        }
+        // keep the blocks in program order (see tile_body): the fences do not change the words
+        fence_words<T::YWI * T::BH>(&in.y[0][0]);
+        fence_words<T::CWI>(in.cb);
+        fence_words<T::CWI>(in.cr);
+        asm volatile("" : "+v"(bn.rmin), "+v"(bn.rmax), "+v"(bn.gmin), "+v"(bn.gmax), "+v"(bn.bmin), "+v"(bn.bmax));
+    }
+    return bn;
+}
+
+// the window's cell ranges live in the wave's 32-byte LDS scratch (they are only read on the second-level path)
+DEV bool cells_hold(int scratch_off, const Bnd &b)
+{
+    const float4 lo = *(const float4 *)(smem + scratch_off);        // r_lo, g_lo, b_lo, r_hi
+    const float2 hi = *(const float2 *)(smem + scratch_off + 16);   // g_hi, b_hi
+    const bool ok = b.rmin >= lo.x && b.rmax <= lo.w && b.gmin >= lo.y && b.gmax <= hi.x && b.bmin >= lo.z && b.bmax <= hi.y;
+    return __all(ok);
+}
+
+// ---------------------------------------------------------------- restage
+DEV uint32_t shx(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+DEV float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+DEV float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+template <int WIN> DEV int lo_of(uint32_t mn) { const int a = (int)(mn & 0xffffu), b = (int)(mn >> 16); const int v = a < b ? a : b; return WIN ? v : v >> 8; }
+template <int WIN> DEV int hi_of(uint32_t mx) { const int a = (int)(mx & 0xffffu), b = (int)(mx >> 16); const int v = a > b ? a : b; return WIN ? v : v >> 8; }
+template <int WIN> DEV uint32_t pack_lo(int v) { const uint32_t h = WIN ? (uint32_t)v : (uint32_t)v << 8; return h | (h << 16); }
+template <int WIN> DEV uint32_t pack_hi(int v) { const uint32_t h = WIN ? (uint32_t)v : ((uint32_t)v << 8) | 0xffu; return h | (h << 16); }
+
+// Neither test vouches for the tile: stage a new window around the tile's EXACT cells (spare cells on the two
+// chroma-like axes as capacity allows, the luma-like axis gets the rest), then look for the largest raw box around the
+// tile's raw extremes whose conservative cell map (map_box) lies inside what was staged: that box is what the cheap
+// first-level test of the following tiles runs against (it may come out empty for very noisy content; those tiles then
+// pay the second level).  Returns false (W untouched; the caller runs the global-gather body for this tile) when the
+// tile's colours do not fit a window, or a raw code lies above 2^din - 1.
+template <int WIN, int INTERP, int PRE, int V>
+DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext &e_, const Bnd &bn_, int slice_off,
+                 int scratch_off, int lane)
+{
+    using N = Node<INTERP, V>;
+    constexpr int kLN = N::lds;
+    Ext e = e_;
+    Bnd bn = bn_;
+    // side-effect free reductions would be hoisted out of the (rare) miss branch into every tile
+    asm volatile("" : "+v"(e.ymin), "+v"(e.ymax), "+v"(e.cbmin), "+v"(e.cbmax), "+v"(e.crmin), "+v"(e.crmax));
+    asm volatile("" : "+v"(bn.rmin), "+v"(bn.rmax), "+v"(bn.gmin), "+v"(bn.gmax), "+v"(bn.bmin), "+v"(bn.bmax));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        e.ymin = pk_min(e.ymin, shx(e.ymin, m)); e.ymax = pk_max(e.ymax, shx(e.ymax, m));
+        e.cbmin = pk_min(e.cbmin, shx(e.cbmin, m)); e.cbmax = pk_max(e.cbmax, shx(e.cbmax, m));
+        e.crmin = pk_min(e.crmin, shx(e.crmin, m)); e.crmax = pk_max(e.crmax, shx(e.crmax, m));
+    }
+    const int y0 = uni(lo_of<WIN>(e.ymin)), y1 = uni(hi_of<WIN>(e.ymax));
+    const int cb0 = uni(lo_of<WIN>(e.cbmin)), cb1 = uni(hi_of<WIN>(e.cbmax));
+    const int cr0 = uni(lo_of<WIN>(e.crmin)), cr1 = uni(hi_of<WIN>(e.crmax));
+    const int mr = TG.max_raw;
+    if (y1 > mr || cb1 > mr || cr1 > mr) return false;
+    const int cap = TG.win_nodes;
+    int ng = 0, nb = 0, sr = 1, nr = 0, r0 = 0, g0 = 0, b0 = 0;
+    int by0 = 1, by1 = 0, bcb0 = 1, bcb1 = 0, bcr0 = 1, bcr1 = 0;             // raw box of the first-level test; empty so far
+    bool placed = false;
+    const float cell_y = L.maxf / (L.lut_max * K.ky * (PRE ? K.py : 1.0f));   // raw codes per lattice cell along luma
+    const int unit = (mr + 1) >> 8;                                            // one 8-bit code in raw codes
+    // (1) A window that covers the conservative image of the tile's raw box plus a margin: the tiles that follow then pass
+    //     the cheap first-level test.  Margins from generous to none; the first whose cells fit the capacity wins.
+#pragma unroll 1
+    for (int t = 0; t < 4 && !placed; t++) {
+        const int mc = t == 0 ? 2 * unit : (t == 1 ? unit : (t == 2 ? (unit + 3) / 4 : 0));
+        const int my = t == 3 ? 0 : (int)((t == 0 ? 2.0f : (t == 1 ? 1.0f : 0.3f)) * cell_y);
+        const int ty0 = max(y0 - my, 0), ty1 = min(y1 + my, mr);
+        const int tcb0 = max(cb0 - mc, 0), tcb1 = min(cb1 + mc, mr), tcr0 = max(cr0 - mc, 0), tcr1 = min(cr1 + mc, mr);
+        const Cells c = map_box<INTERP, PRE, V>(L, K, TG, (float)ty0, (float)ty1, (float)tcb0, (float)tcb1, (float)tcr0, (float)tcr1);
+        // corners: r..r+1, (g-r)-1..(g-r)+1, (b-r)-1..(b-r)+1
+        const int need_r = uni(c.r1 - c.r0 + 2), need_g = uni(c.g1 - c.g0 + 3), need_b = uni(c.b1 - c.b0 + 3);
+        if (need_r < 2 || need_g < 3 || need_b < 3 || need_g > 128 || need_b > 128) continue;
+        // odd row and plane strides: the nodes of neighbouring cells (the ones a wave reads together) differ by +-1, +-nb,
+        // +-(sr - nb - 1) and small sums of those -- kept away from multiples of 16 nodes, i.e. from the same LDS banks
+        const int nb_ = need_b | 1;
+        const int sr_ = (need_g * nb_) | 1, nr_ = cap / sr_;
+        if (nr_ < need_r) continue;
+        ng = need_g; nb = nb_; sr = sr_; nr = nr_;
+        r0 = uni(c.r0) - ((nr - need_r) >> 1); g0 = uni(c.g0) - 1; b0 = uni(c.b0) - 1;
+        by0 = ty0; by1 = ty1; bcb0 = tcb0; bcb1 = tcb1; bcr0 = tcr0; bcr1 = tcr1;
+        placed = true;
+        // the luma-like axis got whatever capacity was left: widen the luma range of the box to match, if the map agrees
+        const int room = (nr - need_r) >> 1;
+        if (room > 0) {
+            const int my2 = my + (int)(0.8f * (float)room * cell_y);
+            const int uy0 = max(y0 - my2, 0), uy1 = min(y1 + my2, mr);
+            const Cells c2 = map_box<INTERP, PRE, V>(L, K, TG, (float)uy0, (float)uy1, (float)tcb0, (float)tcb1, (float)tcr0, (float)tcr1);
+            const bool fits = uni((int)(c2.r0 >= r0 && c2.r1 <= r0 + nr - 2 && c2.g0 >= g0 + 1 && c2.g1 <= g0 + ng - 2 &&
+                                        c2.b0 >= b0 + 1 && c2.b1 <= b0 + nb - 2)) != 0;
+            if (fits) { by0 = uy0; by1 = uy1; }
+        }
+    }
+    if (!placed) {
+        // (2) The raw box is too loose a description of this tile (an edge between two colours: Cb and Cr move together,
+        //     the box spans every combination).  Stage around the tile's EXACT cells; the first-level box stays empty and
+        //     the tiles that follow are vouched for by the second-level test.
+        const int rmin = uni((int)wave_min(bn.rmin)), rmax = uni((int)wave_max(bn.rmax));
+        const int gmin = uni((int)wave_min(bn.gmin)), gmax = uni((int)wave_max(bn.gmax));
+        const int bmin = uni((int)wave_min(bn.bmin)), bmax = uni((int)wave_max(bn.bmax));
+        const int need_r = rmax - rmin + 2, need_g = gmax - gmin + 3, need_b = bmax - bmin + 3;
+        int spare = 1;
+        for (;;) {                                   // one spare cell on each side of the chroma-like axes if it fits
+            ng = need_g + 2 * spare; nb = (need_b + 2 * spare) | 1;
+            sr = (ng * nb) | 1;
+            nr = cap / sr;
+            if (nr >= need_r + 2 * spare || spare == 0) break;
+            spare--;
+        }
+        if (need_r > nr || ng > 128 || nb > 128) return false;
+        r0 = rmin - ((nr - need_r) >> 1);
+        g0 = gmin - 1 - spare;
+        b0 = bmin - 1 - spare;
+    }
+    // cells whose 8 corners are staged
+    const int wr0 = r0, wr1 = r0 + nr - 2, wg0 = g0 + 1, wg1 = g0 + ng - 2, wb0 = b0 + 1, wb1 = b0 + nb - 2;
+
+    const int n1 = L.n1, nmax = L.n1 - 1;
+    const int plane = ng * nb, total = nr * plane;
+    // i -> (ir, ig, ib): floor(i/d) = umulhi(i, ceil(2^32/d)), exact while i*d < 2^32 (i < 32768, d <= 16641)
+    const unsigned inv_plane = (unsigned)((0x100000000ull + plane - 1) / plane);
+    const unsigned inv_nb = (unsigned)((0x100000000ull + nb - 1) / nb);
+    // Batches of kB nodes per lane: all kB global reads are issued before the first LDS write, so a restage costs about
+    // one L2 round trip per batch instead of one per node (the wave is stalled meanwhile; 4 waves per SIMD cannot hide it).
+    constexpr int kB = 6;
+    for (int base = 0; base < total; base += 64 * kB) {
+        int dst[kB];
+        typename std::conditional<N::fast, uint2, float4>::type val[kB];
+#pragma unroll
+        for (int k = 0; k < kB; k++) {
+            const int i = min(base + k * 64 + lane, total - 1);              // the last batch re-reads the final node: harmless
+            const int ir = (int)__umulhi((unsigned)i, inv_plane), rem = i - ir * plane;
+            const int ig = (int)__umulhi((unsigned)rem, inv_nb), ib = rem - ig * nb;
+            int r = r0 + ir, g = r + g0 + ig, b = r + b0 + ib;
+            // nodes outside the cube are never referenced by a valid pixel: clamp to stay inside the lattice
+            r = min(max(r, 0), nmax); g = min(max(g, 0), nmax); b = min(max(b, 0), nmax);
+            const int src = (r * n1 + g) * n1 + b;
+            dst[k] = slice_off + kLN * (ir * sr + ig * nb + ib);
+            if constexpr (N::fast) val[k] = L.lat16[src];
+            else val[k] = L.lat[src];
+        }
+#pragma unroll
+        for (int k = 0; k < kB; k++) {
+            char *q = smem + dst[k];
+            if constexpr (N::fast) *(uint2 *)q = val[k];
+            else if constexpr (kLN == 16) *(float4 *)q = val[k];
+            else { ((float *)q)[0] = val[k].x; ((float *)q)[1] = val[k].y; ((float *)q)[2] = val[k].z; }
+        }
+    }
+    if (lane == 0) {
+        *(float4 *)(smem + scratch_off) = make_float4((float)wr0, (float)wg0, (float)wb0, (float)wr1);
+        *(float2 *)(smem + scratch_off + 16) = make_float2((float)wg1, (float)wb1);
+    }
+    // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pr-b0)
+    W.o_r = kLN * (sr - nb - 1); W.o_g = kLN * nb;
+    W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)kLN;
+    W.fc = (float)(lds_base() + slice_off - kLN * (r0 * sr + g0 * nb + b0));
+    if (by1 >= by0) {
+        W.ylo = pack_lo<WIN>(by0); W.yhi = pack_hi<WIN>(by1);
+        W.cblo = pack_lo<WIN>(bcb0); W.cbhi = pack_hi<WIN>(bcb1);
+        W.crlo = pack_lo<WIN>(bcr0); W.crhi = pack_hi<WIN>(bcr1);
+    } else {
+        W.ylo = W.cblo = W.crlo = 0xffffffffu; W.yhi = W.cbhi = W.crhi = 0u;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- one pixel
+struct PxC {
+    int a;                  // byte address (LDS) or byte offset (global) of the c000 tap
+    int oa, oz;             // tetrahedral: byte offsets of the 2nd and 3rd taps
+    float w0, w1, w2, w3;   // tetrahedral weights; trilinear keeps d.r, d.g, d.b in w0..w2
+};
+struct Rgb3 { float r, g, b; };
+
+template <bool LDS, int INTERP, int V>
+DEV PxC px_finish(const LutConsts &L, const Win &W, const Crd &cr, const Crd &cg, const Crd &cb)
+{
+    using N = Node<INTERP, V>;
+    constexpr int nb_ = LDS ? N::lds : N::glb;
+    PxC c;
+    if constexpr (LDS) {
+        // exact in fp32: every term is an integer well below 2^24; the box test guarantees the address is inside the slice
+        c.a = (int)fma_(cr.p, W.fr, fma_(cg.p, W.fg, fma_(cb.p, W.fb, W.fc)));
+    } else {
+        c.a = (((int)cr.p * L.n1 + (int)cg.p) * L.n1 + (int)cb.p) * nb_;
+    }
+    c.oa = c.oz = 0;
+    c.w0 = c.w1 = c.w2 = c.w3 = 0.0f;
+    if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
+        c.w0 = cr.d; c.w1 = cg.d; c.w2 = cb.d;
+    } else if constexpr (INTERP == LUTR_INTERP_TETRAHEDRAL) {
+        // FFmpeg's six branches all evaluate (1-x) c000 + (x-y) cA + (y-z) cB + z c111 with (x,y,z) the fractions sorted
+        // descending; ties only ever choose between taps whose weight is exactly 0 (finite lattice), so the sorted form is
+        // bit-identical.
+        const float dr = cr.d, dg = cg.d, db = cb.d;
+        const float x = fmaxf(fmaxf(dr, dg), db), y = med3(dr, dg, db), z = fminf(fminf(dr, dg), db);
+        const bool rg = dr > dg, gb = dg > db, rb = dr > db;
+        const int o_r = LDS ? W.o_r : nb_ * L.n1 * L.n1, o_g = LDS ? W.o_g : nb_ * L.n1, o_b = nb_;
+        const int z_r = o_g + o_b, z_g = o_r + o_b, z_b = o_r + o_g;         // o111 minus the step of the smallest fraction
+        c.oa = (rg && rb) ? o_r : (gb ? o_g : o_b);
+        c.oz = (gb && rb) ? z_b : (rg ? z_g : z_r);
+        c.w0 = 1.0f - x; c.w1 = x - y; c.w2 = y - z; c.w3 = z;
+    }
+    return c;
+}
+
+// strict taps: one node as floats
+template <bool LDS, int NB>
+DEV f4 tap(const LutConsts &L, int a)
+{
+    if constexpr (LDS && NB == 16) {
+        return *(const __attribute__((address_space(3))) f4 *)(uintptr_t)(unsigned)a;
+    } else if constexpr (LDS) {
+        const __attribute__((address_space(3))) float *p = (const __attribute__((address_space(3))) float *)(uintptr_t)(unsigned)a;
+        f4 v; v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = 0.0f;
+        return v;
+    } else {
+        return *(const f4 *)((const char *)L.lat + a);
+    }
+}
+// fast taps: one node as two words {r | g << 16, b} of fp16
+template <bool LDS>
+DEV u2 tap16(const LutConsts &L, int a)
+{
+    if constexpr (LDS) return *(const __attribute__((address_space(3))) u2 *)(uintptr_t)(unsigned)a;
+    else return *(const u2 *)((const char *)L.lat16 + a);
+}
+
+DEV float tlerp(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
+
+// The taps of one pixel, loaded in one go so that several pixels' reads are in flight together (tile_body phases).
+template <int INTERP, int V> struct Taps {
+    static constexpr int n = INTERP == LUTR_INTERP_TRILINEAR ? 8 : (INTERP == LUTR_INTERP_NEAREST ? 1 : 4);
+    typename std::conditional<V == V_FAST, u2, f4>::type t[n];
+};
+
+template <bool LDS, int INTERP, int V>
+DEV Taps<INTERP, V> px_taps(const LutConsts &L, const Win &W, const PxC &c)
+{
+    using N = Node<INTERP, V>;
+    constexpr int nb_ = LDS ? N::lds : N::glb;
+    const int o_r = LDS ? W.o_r : nb_ * L.n1 * L.n1, o_g = LDS ? W.o_g : nb_ * L.n1;
+    const int a = c.a;
+    Taps<INTERP, V> T;
+    auto ld = [&](int addr) {
+        if constexpr (N::fast) return tap16<LDS>(L, addr);
+        else return tap<LDS, nb_>(L, addr);
+    };
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) {
+        T.t[0] = ld(a);
+    } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
+        const int ag = a + o_g, ar = a + o_r, arg = ar + o_g;
+        T.t[0] = ld(a); T.t[1] = ld(a + nb_); T.t[2] = ld(ag); T.t[3] = ld(ag + nb_);       // c000 c001 c010 c011
+        T.t[4] = ld(ar); T.t[5] = ld(ar + nb_); T.t[6] = ld(arg); T.t[7] = ld(arg + nb_);   // c100 c101 c110 c111
+    } else {
+        T.t[0] = ld(a); T.t[1] = ld(a + c.oa); T.t[2] = ld(a + c.oz); T.t[3] = ld(a + o_r + o_g + nb_);
+    }
+    return T;
+}
+
+// lattice value as the integer code it quantises to, held as float
+template <int INTERP, int V>
+DEV Rgb3 px_blend(const LutConsts &L, const PxC &c, const Taps<INTERP, V> &T)
+{
+    Rgb3 v;
+    if constexpr (V == V_FAST) {
+        // nodes are fp16 of (lattice * M): the blend IS the code before truncation.  v_fma_mix_f32 takes the fp16 tap as it
+        // is (exact conversion inside the instruction), fp32 weight, fp32 accumulator: one rounding per step.
+        if constexpr (INTERP == LUTR_INTERP_NEAREST) {
+            v.r = mix0_lo(1.0f, T.t[0].x); v.g = mix0_hi(1.0f, T.t[0].x); v.b = mix0_lo(1.0f, T.t[0].y);
+        } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
+            const float dr = c.w0, dg = c.w1, db = c.w2;
+#define TRI16(SUB, LERP, W_, out) \
+            { \
+                const float c00 = LERP(SUB(T.t[4].W_, T.t[0].W_), dr, T.t[0].W_), c10 = LERP(SUB(T.t[6].W_, T.t[2].W_), dr, T.t[2].W_); \
+                const float c01 = LERP(SUB(T.t[5].W_, T.t[1].W_), dr, T.t[1].W_), c11 = LERP(SUB(T.t[7].W_, T.t[3].W_), dr, T.t[3].W_); \
+                const float c0 = fma_(c10 - c00, dg, c00), c1 = fma_(c11 - c01, dg, c01); \
+                out = fma_(c1 - c0, db, c0); \
+            }
+            TRI16(hsub_lo, hlerp_lo, x, v.r) TRI16(hsub_hi, hlerp_hi, x, v.g) TRI16(hsub_lo, hlerp_lo, y, v.b)
+#undef TRI16
+        } else {
+            v.r = mix_lo(c.w3, T.t[3].x, mix_lo(c.w2, T.t[2].x, mix_lo(c.w1, T.t[1].x, mix0_lo(c.w0, T.t[0].x))));
+            v.g = mix_hi(c.w3, T.t[3].x, mix_hi(c.w2, T.t[2].x, mix_hi(c.w1, T.t[1].x, mix0_hi(c.w0, T.t[0].x))));
+            v.b = mix_lo(c.w3, T.t[3].y, mix_lo(c.w2, T.t[2].y, mix_lo(c.w1, T.t[1].y, mix0_lo(c.w0, T.t[0].y))));
+        }
+        return v;
+    } else {
+        if constexpr (INTERP == LUTR_INTERP_NEAREST) {
+            v.r = T.t[0].x; v.g = T.t[0].y; v.b = T.t[0].z;
+        } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
+            const float dr = c.w0, dg = c.w1, db = c.w2;
+#define TRI(ch, out) \
+            { \
+                const float c00 = tlerp(T.t[0].ch, T.t[4].ch, dr), c10 = tlerp(T.t[2].ch, T.t[6].ch, dr); \
+                const float c01 = tlerp(T.t[1].ch, T.t[5].ch, dr), c11 = tlerp(T.t[3].ch, T.t[7].ch, dr); \
+                const float c0 = tlerp(c00, c10, dg), c1 = tlerp(c01, c11, dg); \
+                out = tlerp(c0, c1, db); \
+            }
+            TRI(x, v.r) TRI(y, v.g) TRI(z, v.b)
+#undef TRI
+        } else {
+            v.r = c.w0 * T.t[0].x + c.w1 * T.t[1].x + c.w2 * T.t[2].x + c.w3 * T.t[3].x;
+            v.g = c.w0 * T.t[0].y + c.w1 * T.t[1].y + c.w2 * T.t[2].y + c.w3 * T.t[3].y;
+            v.b = c.w0 * T.t[0].z + c.w1 * T.t[1].z + c.w2 * T.t[2].z + c.w3 * T.t[3].z;
+        }
+        v.r *= L.maxf; v.g *= L.maxf; v.b *= L.maxf;
+        return v;
+    }
+}
+
+// (int)(v * M) clipped to [0, M]; V >= V_UNIT: every lattice node lies in [0, 1], the truncation alone lands in [0, M]
+// (all weights and nodes >= 0, rounding of products and sums is monotone): the clip is dead code.
+template <int V>
+DEV Rgb3 px_quant(const LutConsts &L, const Rgb3 &v)
+{
+    Rgb3 o;
+    if constexpr (V >= V_UNIT) { o.r = truncf(v.r); o.g = truncf(v.g); o.b = truncf(v.b); }
+    else { o.r = med3(truncf(v.r), 0.0f, L.maxf); o.g = med3(truncf(v.g), 0.0f, L.maxf); o.b = med3(truncf(v.b), 0.0f, L.maxf); }
+    return o;
+}
+
+template <bool DEAD> DEV float ofloor(float v, float hi) { if constexpr (DEAD) return v; else return fminf(v, hi); }
+
+// ---------------------------------------------------------------- tile body
+// Coordinates of the four pixels of a group (phase A): twelve table reads (or their computed twins) issued back to back.
+struct GroupCrd { Crd r[4], g[4], b[4]; };
+
+template <bool LDS, int WIN, int WOUT, int CSX, int CSY, int INTERP, int PRE, int V>
+DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, const TileIn<WIN, WOUT, CSX, CSY> &in, int g, GroupCrd &q)
+{
+    using T = Tile<WIN, WOUT, CSX, CSY>;
+    constexpr int GW = 4 / T::BH, NCG = (GW >> CSX) > 0 ? (GW >> CSX) : 1;
+    float rv[NCG], gv[NCG], bu[NCG];
+#pragma unroll
+    for (int c = 0; c < NCG; c++) {
+        const int j = g * NCG + c;
+        float cbv = wsample<WIN>(in.cb, j), crv = wsample<WIN>(in.cr, j);
+        if constexpr (PRE) {
+            cbv = cfloor(fma_(K.pc, cbv, K.pcb), K.pre_max);
+            crv = cfloor(fma_(K.pc, crv, K.pcb), K.pre_max);
+        }
+        const float cbd = cbv - K.coff, crd = crv - K.coff;
+        rv[c] = K.krv * crd; gv[c] = fma_(K.kgu, cbd, K.kgv * crd); bu[c] = K.kbu * cbd;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
+        float yv = wsample<WIN>(in.y[dy], i);
+        if constexpr (PRE) yv = cfloor(fma_(K.py, yv, K.pyb), K.pre_max);
+        const float yy = fma_(K.ky, yv, K.yb);
+        if constexpr (V >= V_TAB) {
+            // clip(floor(v), 0, M): v_cvt_u32_f32 floors and saturates negatives to 0; the table is padded past M
+            unsigned ri = (unsigned)(yy + rv[c]), gi = (unsigned)(yy + gv[c]), bi = (unsigned)(yy + bu[c]);
+            if constexpr (!LDS) {           // the gather body also serves tiles with raw codes nobody vouched for
+                const unsigned top = (unsigned)(TG.tab_entries - 1);
+                ri = min(ri, top); gi = min(gi, top); bi = min(bi, top);
+            }
+            q.r[p] = crd_table(ri); q.g[p] = crd_table(gi); q.b[p] = crd_table(bi);
+        } else {
+            const float rq = cfloor(yy + rv[c], K.max_l), gq = cfloor(yy + gv[c], K.max_l), bq = cfloor(yy + bu[c], K.max_l);
+            q.r[p] = crd_compute<INTERP>(L, rq, L.sc[0]); q.g[p] = crd_compute<INTERP>(L, gq, L.sc[1]);
+            q.b[p] = crd_compute<INTERP>(L, bq, L.sc[2]);
+        }
+    }
+}
+
+#ifndef LUTR_T2_PIPE
+#define LUTR_T2_PIPE 1            // software pipeline across pixel groups: group g+1's coordinate reads are issued before group g's blend
+#endif
+#ifndef LUTR_T2_TB_FAST
+#define LUTR_T2_TB_FAST 4
+#endif
+
+// One tile.  Every LDS result is requested well before it is used, inside the wave: with four waves per SIMD (the
+// register budget) the hardware alone cannot hide an LDS round trip per pixel.  Order per group g:
+//   A(g+1)  coordinate reads of the next group      (12 ds_read_b64, consumed one group later)
+//   B(g)    tap addresses + weights, then tap reads  (TB pixels' taps in flight together)
+//   C(g)    blends, truncation, RGB -> YUV, packing
+// sched_barrier keeps the machine scheduler from sinking the reads back next to their uses; the zero-instruction
+// fences at the end of a group keep instruction selection from hoisting every group to the top (> 1000 spilled registers).
+template <bool LDS, int WIN, int WOUT, int CSX, int CSY, int INTERP, int PRE, int V>
+DEV void tile_body(const LutConsts &L, const YuvConsts &K, const Win &W, const Geom &TG, TileIn<WIN, WOUT, CSX, CSY> &in,
+                   TileOut<WIN, WOUT, CSX, CSY> &out)
+{
+    using T = Tile<WIN, WOUT, CSX, CSY>;
+    // a group = 4 pixels: all BH rows of GW columns; it owns NCG chroma samples
+    constexpr int GW = 4 / T::BH, NG = T::PXT / GW, NCG = (GW >> CSX) > 0 ? (GW >> CSX) : 1;
+    constexpr bool kDead = V >= V_UNIT;          // launcher checked the RGB->YUV maxima too (out_clip_dead)
+    // measured (UHD yuv420p10le tetrahedral, Gpx/s): strict 503 with the pipeline, 484 without; fast 458 with (the extra live
+    // coordinates push its 4-pixel tap batches into spills), 550-565 without
+    constexpr bool kPipe = LUTR_T2_PIPE && LDS && V >= V_TAB && V != V_FAST;
+    constexpr int TB = INTERP == LUTR_INTERP_TRILINEAR ? (V == V_FAST ? 2 : 1)
+                                                       : (INTERP == LUTR_INTERP_NEAREST ? 4 : (V == V_FAST ? LUTR_T2_TB_FAST : 2));
+    GroupCrd cq[2];
+    if constexpr (kPipe) group_coords<LDS, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, TG, in, 0, cq[0]);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        GroupCrd &q = cq[kPipe ? (g & 1) : 0];
+        if constexpr (kPipe) {
+            if (g + 1 < NG) group_coords<LDS, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, TG, in, g + 1, cq[(g + 1) & 1]);
+        } else {
+            group_coords<LDS, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, TG, in, g, q);
+        }
+#if LUTR_T2_PHASES
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        Rgb3 o[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; qb += TB) {
+            PxC pc[TB];
+            Taps<INTERP, V> tp[TB];
+#pragma unroll
+            for (int t = 0; t < TB; t++) {
+                pc[t] = px_finish<LDS, INTERP, V>(L, W, q.r[qb + t], q.g[qb + t], q.b[qb + t]);
+                tp[t] = px_taps<LDS, INTERP, V>(L, W, pc[t]);
+            }
+#if LUTR_T2_PHASES
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int t = 0; t < TB; t++) o[qb + t] = px_quant<V>(L, px_blend<INTERP, V>(L, pc[t], tp[t]));
+        }
+        float rs[NCG], gs[NCG], bs[NCG];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
+            if (dy == 0 && ((p % GW) & (T::BW - 1)) == 0) { rs[c] = o[p].r; gs[c] = o[p].g; bs[c] = o[p].b; }
+            else { rs[c] += o[p].r; gs[c] += o[p].g; bs[c] += o[p].b; }
+            wput<WOUT>(out.y[dy], i, ofloor<kDead>(fma_(K.cyr, o[p].r, fma_(K.cyg, o[p].g, fma_(K.cyb, o[p].b, K.yob))), K.max_o));
+        }
+#pragma unroll
+        for (int c = 0; c < NCG; c++) {
+            const int j = g * NCG + c;
+            wput<WOUT>(out.cb, j, ofloor<kDead>(fma_(K.cbr, rs[c], fma_(K.cbg, gs[c], fma_(K.cbb, bs[c], K.cob))), K.max_o));
+            wput<WOUT>(out.cr, j, ofloor<kDead>(fma_(K.crr, rs[c], fma_(K.crg, gs[c], fma_(K.crb, bs[c], K.cob))), K.max_o));
+        }
+        fence_words<T::YWI * T::BH>(&in.y[0][0]);
+        fence_words<T::CWI>(in.cb);
+        fence_words<T::CWI>(in.cr);
+        fence_words<T::YWO * T::BH>(&out.y[0][0]);
+        fence_words<T::CWO>(out.cb);
+        fence_words<T::CWO>(out.cr);
+    }
+}
+
+// ---------------------------------------------------------------- work distribution
+DEV bool chunk_at(const Geom &TG, unsigned c, int &fr, int &sx, int &ry, int &rem)
+{
+    if (c >= (unsigned)TG.nchunks) return false;
+    const int per_frame = TG.nrc * TG.nsx;
+    fr = (int)c / per_frame;
+    const int r = (int)c - fr * per_frame;
+    const int rc = r / TG.nsx;
+    sx = r - rc * TG.nsx;
+    ry = rc * TG.ch;
+    rem = min(TG.ch, TG.nry - ry);
+    return true;
+}
+
+// every wave takes its first chunk by its id (a burst of atomics on one address at kernel start serialises in the L2)
+DEV bool claim_chunk(const Geom &TG, int lane, int &fr, int &sx, int &ry, int &rem, bool &first)
+{
+    unsigned c = 0;
+    if (first) {
+        first = false;
+        c = (unsigned)((int)(blockIdx.x * LUTR_T2_WPB) + uni((int)(threadIdx.x >> 6)));
+        if (c < (unsigned)TG.nchunks) return chunk_at(TG, c, fr, sx, ry, rem);
+    }
+    if (lane == 0) c = atomicAdd(TG.queue, 1u);
+    c = (unsigned)uni((int)c);
+    return chunk_at(TG, c, fr, sx, ry, rem);
+}
+
+template <int WIN, int WOUT, int CSX, int CSY, int INTERP, int PRE, int V>
+__global__ __launch_bounds__(64 * LUTR_T2_WPB, LUTR_T2_WAVES_PER_EU)
+void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
+{
+    using T = Tile<WIN, WOUT, CSX, CSY>;
+    using N = Node<INTERP, V>;
+    LutConsts L = L_;
+    YuvConsts K = K_;
+    // a wave-uniform constant used by several VALU ops per pixel is worth a VGPR (an SGPR operand halves the issue rate
+    // of plain fp32 ops on gfx950, tools/ubench); the trilinear bodies have no registers to spare
+#ifndef LUTR_T2_PIN
+#define LUTR_T2_PIN 2
+#endif
+    if constexpr (INTERP != LUTR_INTERP_TRILINEAR && LUTR_T2_PIN >= 1) {
+        K.cyr = in_vgpr(K_.cyr); K.cyg = in_vgpr(K_.cyg); K.cyb = in_vgpr(K_.cyb);
+        if constexpr (LUTR_T2_PIN >= 2) { K.ky = in_vgpr(K_.ky); K.yb = in_vgpr(K_.yb); K.yob = in_vgpr(K_.yob); }
+        if constexpr (!N::fast) L.maxf = in_vgpr(L_.maxf);
+    }
+    if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier
+    const int lane = threadIdx.x & 63;
+    const int wib = uni(threadIdx.x >> 6);
+    const int tab_bytes = TG.tab_entries * 8;
+    const int scratch_off = tab_bytes + wib * 32;             // the window's cell ranges (second-level test)
+    const int slice_off = tab_bytes + LUTR_T2_WPB * 32 + wib * TG.win_nodes * N::lds;
+    int fr, sx, ry, rem;                                      // the tile being fetched next
+    bool first = true;
+    if (!claim_chunk(TG, lane, fr, sx, ry, rem, first)) return;
+    const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
+    const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
+    const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
+
+    Win W;
+    W.fr = W.fg = W.fb = W.fc = 0.0f; W.o_r = W.o_g = 0;
+    // empty box: lo > hi in every plane, so the first tile always restages
+    W.ylo = W.cblo = W.crlo = 0xffffffffu; W.yhi = W.cbhi = W.crhi = 0u;
+    constexpr int YIB = T::YWI * 4, YOB = T::YWO * 4, CIB = T::CWI * 4, COB = T::CWO * 4;
+
+    // Input words of a tile.  Idle lanes of edge tiles re-read a valid unit of the same tile.
+    auto load_tile = [&](TileIn<WIN, WOUT, CSX, CSY> &dst, int f, int tsx, int try_) {
+        const int lxc = min(lx, TG.uw - 1 - tsx * lw), lyc = min(ly, TG.urows - 1 - (try_ << lh_log2));
+        const long long urow0 = cr0 + (try_ << lh_log2);                  // wave-uniform
+        const uint8_t *sy = P.s[0] + f * P.sfs[0] + urow0 * T::BH * (long long)P.ss[0] + (long long)tsx * lw * YIB;
+        const uint8_t *scb = P.s[1] + f * P.sfs[1] + urow0 * (long long)P.ss[1] + (long long)tsx * lw * CIB;
+        const uint8_t *scr = P.s[2] + f * P.sfs[2] + urow0 * (long long)P.ss[2] + (long long)tsx * lw * CIB;
+#pragma unroll
+        for (int dy = 0; dy < T::BH; dy++)
+            ldw<T::YWI>(dst.y[dy], sy + (unsigned)((lyc * T::BH + dy) * (int)P.ss[0] + lxc * YIB));
+        ldw<T::CWI>(dst.cb, scb + (unsigned)(lyc * (int)P.ss[1] + lxc * CIB));
+        ldw<T::CWI>(dst.cr, scr + (unsigned)(lyc * (int)P.ss[2] + lxc * CIB));
+    };
+
+    bool have_win = false;
+    unsigned st_tiles = 0, st_miss = 0, st_gather = 0, st_staged = 0, st_level2 = 0;
+#ifdef LUTR_T2_DEBUG_STATS
+    unsigned tk_head = 0, tk_l2 = 0, tk_rest = 0, tk_body = 0, tk_gath = 0, tk_store = 0;
+    unsigned long long tk = __builtin_amdgcn_s_memrealtime();
+#define TK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); acc += (unsigned)(now_ - tk); tk = now_; }
+#else
+#define TK(acc)
+#endif
+#ifndef LUTR_T2_PREFETCH
+#define LUTR_T2_PREFETCH 1
+#endif
+#if LUTR_T2_PREFETCH
+    TileIn<WIN, WOUT, CSX, CSY> nxt;
+    load_tile(nxt, fr, sx, ry);
+#endif
+    for (bool more = true; more;) {
+#if LUTR_T2_PREFETCH
+        TileIn<WIN, WOUT, CSX, CSY> in = nxt;
+#else
+        TileIn<WIN, WOUT, CSX, CSY> in;
+        load_tile(in, fr, sx, ry);
+#endif
+        const int cfr = fr, csx = sx, cry = ry;
+        // Next tile: the one below in this chunk, else the first tile of a newly claimed chunk.  Its loads are issued
+        // NOW, before this tile's stores (vmcnt retires in order).  When the queue is drained the current tile is simply
+        // fetched again, so every path has the same number of memory operations in flight.
+        if (--rem > 0) ry++;
+        else more = claim_chunk(TG, lane, fr, sx, ry, rem, first);
+#if LUTR_T2_PREFETCH
+        load_tile(nxt, fr, sx, ry);
+#endif
+
+#ifndef LUTR_T2_EXP
+#define LUTR_T2_EXP 0             // timing experiments only (wrong pixels): 1 = trust the first window forever, 2 = + no stores, 3 = no body
+#endif
+        const Ext e = extremes<WIN, WOUT, CSX, CSY>(in);
+        bool use_lds = box_holds(W, e);                       // first level: raw extremes against the window's raw box
+        if (LUTR_T2_EXP >= 1 && have_win) use_lds = true;
+        TK(tk_head)
+        if (!use_lds) {
+            st_level2++;
+
+            const Bnd bn = tile_bounds<WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, TG, in);
+            // second level: exact cells against the window's cell ranges (raw codes must be legal for the clamp-free body)
+            const uint32_t top = pack_hi<WIN>(TG.max_raw);
+            const bool legal = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
+            use_lds = have_win && legal && cells_hold(scratch_off, bn);
+            TK(tk_l2)
+            if (!use_lds) {
+                st_miss++;
+                use_lds = restage<WIN, INTERP, PRE, V>(W, L, K, TG, e, bn, slice_off, scratch_off, lane);
+                if (use_lds) { st_staged++; have_win = true; }
+                TK(tk_rest)
+            }
+        }
+        TileOut<WIN, WOUT, CSX, CSY> out;
+        if (LUTR_T2_EXP == 3) {
+#pragma unroll
+            for (int dy = 0; dy < T::BH; dy++)
+#pragma unroll
+                for (int k = 0; k < T::YWO; k++) out.y[dy][k] = in.y[dy][k % T::YWI];
+#pragma unroll
+            for (int k = 0; k < T::CWO; k++) { out.cb[k] = in.cb[k % T::CWI]; out.cr[k] = in.cr[k % T::CWI]; }
+        } else
+        if (use_lds) {
+            tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out); TK(tk_body)
+            if (LUTR_T2_EXP == 4) tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out);
+        }
+        else { tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out); st_gather++; TK(tk_gath) }
+        {
+            // Idle lanes of edge tiles processed a duplicate of a valid unit of this tile (load_tile clamps), so they
+            // store the same bytes to the same place as its owner: no branch, fixed store count.
+            const int lxc = min(lx, TG.uw - 1 - csx * lw), lyc = min(ly, TG.urows - 1 - (cry << lh_log2));
+            const long long urow0 = cr0 + (cry << lh_log2);
+            uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * (long long)P.ds[0] + (long long)csx * lw * YOB;
+            uint8_t *dcb = P.d[1] + cfr * P.dfs[1] + urow0 * (long long)P.ds[1] + (long long)csx * lw * COB;
+            uint8_t *dcr = P.d[2] + cfr * P.dfs[2] + urow0 * (long long)P.ds[2] + (long long)csx * lw * COB;
+            if (LUTR_T2_EXP != 2 || out.cb[0] == 0x12345u) {
+#pragma unroll
+            for (int dy = 0; dy < T::BH; dy++)
+                stw<T::YWO>(dy_ + (unsigned)((lyc * T::BH + dy) * (int)P.ds[0] + lxc * YOB), out.y[dy]);
+            stw<T::CWO>(dcb + (unsigned)(lyc * (int)P.ds[1] + lxc * COB), out.cb);
+            stw<T::CWO>(dcr + (unsigned)(lyc * (int)P.ds[2] + lxc * COB), out.cr);
+            }
+        }
+        st_tiles++;
+        TK(tk_store)
+    }
+#ifdef LUTR_T2_DEBUG_STATS
+    if (TG.stats && lane == 0) {
+        atomicAdd(&TG.stats[4], tk_head >> 4); atomicAdd(&TG.stats[5], tk_l2 >> 4); atomicAdd(&TG.stats[7], tk_rest >> 4);
+        atomicAdd(&TG.stats[8], tk_body >> 4); atomicAdd(&TG.stats[9], tk_gath >> 4); atomicAdd(&TG.stats[10], tk_store >> 4);
+    }
+#endif
+    if (TG.stats && lane == 0) {
+        atomicAdd(&TG.stats[0], st_tiles); atomicAdd(&TG.stats[1], st_miss);
+        atomicAdd(&TG.stats[2], st_gather); atomicAdd(&TG.stats[3], st_staged); atomicAdd(&TG.stats[6], st_level2);
+    }
+}
+
+}  // namespace t2
+
+// ================================================================= launcher
+namespace {
+
+int device_cus()
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+
+void allow_lds(const void *kernel, size_t bytes)
+{
+    static std::set<std::pair<int, const void *>> done;      // the attribute is per device
+    static std::mutex mu;
+    if (bytes <= 65536) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.insert({dev, kernel});
+}
+
+// Largest index (unsigned)(yy + {rv, gv, bu}) can take for raw codes in [0, 2^din - 1]: each sum is monotone in its inputs.
+int table_entries(const YuvConsts &K, int din)
+{
+    const float mr = (float)((1 << din) - 1);
+    auto pre = [&](float v, float a, float b) { return K.pre != 0.0f ? fminf(fmaxf(floorf(fmaf(a, v, b)), 0.0f), K.pre_max) : v; };
+    const float y1 = pre(mr, K.py, K.pyb), c0 = pre(0.0f, K.pc, K.pcb), c1 = pre(mr, K.pc, K.pcb);
+    const float yy = fmaf(K.ky, y1, K.yb);
+    const float r = yy + K.krv * (c1 - K.coff), g = yy + fmaf(K.kgu, c0 - K.coff, K.kgv * (c0 - K.coff)), b = yy + K.kbu * (c1 - K.coff);
+    const float top = fmaxf(fmaxf(r, g), fmaxf(b, K.max_l));
+    return ((int)top + 3) & ~1;           // even: the window slices behind the table stay 16-byte aligned (ds_read_b128)
+}
+
+bool out_clip_dead(const YuvConsts &K, int chroma_n)
+{
+    const float m = K.max_l, mn = K.max_l * (float)chroma_n;
+    auto hi = [](float c, float v) { return c > 0.0f ? v : 0.0f; };
+    const float y = fmaf(K.cyr, hi(K.cyr, m), fmaf(K.cyg, hi(K.cyg, m), fmaf(K.cyb, hi(K.cyb, m), K.yob)));
+    const float cb = fmaf(K.cbr, hi(K.cbr, mn), fmaf(K.cbg, hi(K.cbg, mn), fmaf(K.cbb, hi(K.cbb, mn), K.cob)));
+    const float cr = fmaf(K.crr, hi(K.crr, mn), fmaf(K.crg, hi(K.crg, mn), fmaf(K.crb, hi(K.crb, mn), K.cob)));
+    const float lim = K.max_o + 1.0f;
+    return y < lim && cb < lim && cr < lim;
+}
+
+}  // namespace
+
+#ifndef LUTR_T2_ONLY
+#define LUTR_T2_ONLY 0      // 1: build the headline instance alone (development)
+#endif
+
+// Which variant serves this call?
+static int tile2_variant(const LutConsts &L, const YuvConsts &K, int lut_depth, int csx, int csy, bool fast)
+{
+    const bool eq = L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2];
+    const bool tab = eq && lut_depth <= 10 && !getenv("LUTR_NO_TAB");
+    const bool unit = L.unit && out_clip_dead(K, 1 << (csx + csy));
+    if (fast && tab && unit && L.lat16) return t2::V_FAST;
+    if (tab && unit) return t2::V_UNIT;
+    if (tab) return t2::V_TAB;
+    return t2::V_GEN;
+}
+
+const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P, const FrameGeom &G,
+                             int din, int dout, int lut_depth, int csx, int csy, int mode, bool fast, unsigned *stats, unsigned *queue)
+{
+    using namespace t2;
+    constexpr int win = LUTR_T2_WI, wout = LUTR_T2_WO;
+    if ((din > 8) != win || (dout > 8) != wout || csx != LUTR_T2_X || csy != LUTR_T2_Y) return nullptr;
+    const int pxt = win ? 8 : 16;
+    const bool pre = K.pre != 0.0f;
+    const int v = tile2_variant(L, K, lut_depth, csx, csy, fast);
+    if (pre && v != V_UNIT && v != V_FAST) return nullptr;
+    // nearest has no blend to speed up and no prologue instances: strict clip-free kernel, or the round-1 path
+    if (mode == LUTR_INTERP_NEAREST && pre) return nullptr;
+    const int vv = (mode == LUTR_INTERP_NEAREST && v == V_FAST) ? V_UNIT : v;
+    for (int i = 0; i < 3; i++)
+        if (P.sfs[i] < 0 || P.dfs[i] < 0) return nullptr;
+
+    Geom tg;
+    const int uw = G.w / pxt, urows = G.rows >> csy;
+    int best = 6;
+    double best_eff = -1.0;
+    for (int l = 6; l >= 2; l--) {
+        const int lw = 1 << l, lh = 64 >> l;
+        const double eff = ((double)uw / (((uw + lw - 1) / lw) * lw)) * ((double)urows / (((urows + lh - 1) / lh) * lh));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = l; }
+    }
+    tg.lw_log2 = best; tg.uw = uw; tg.urows = urows;
+    tg.nsx = (uw + (1 << best) - 1) >> best;
+    tg.nry = (urows + (64 >> best) - 1) / (64 >> best);
+    int waves_per_cu = 16;
+    if (const char *e = getenv("LUTR_WAVES_PER_CU")) { const int c = atoi(e); if (c >= LUTR_T2_WPB && c <= 32 && c % LUTR_T2_WPB == 0) waves_per_cu = c; }
+    const int max_waves = device_cus() * waves_per_cu;
+    int ch = 16;
+    if (const char *e = getenv("LUTR_CHUNK")) { const int c = atoi(e); if (c >= 1 && c <= 256) ch = c; }
+    while (ch > 1 && (long long)G.nframes * tg.nsx * ((tg.nry + ch - 1) / ch) < max_waves / 4) ch >>= 1;
+    tg.ch = ch; tg.nrc = (tg.nry + ch - 1) / ch; tg.nchunks = G.nframes * tg.nrc * tg.nsx;
+    tg.tab_entries = vv >= V_TAB ? table_entries(K, din) : 0;
+    tg.max_raw = (1 << din) - 1;
+    const int node = vv == V_FAST ? 8 : (mode == LUTR_INTERP_TRILINEAR ? 16 : 12);
+    const int blocks_per_cu = waves_per_cu / LUTR_T2_WPB > 0 ? waves_per_cu / LUTR_T2_WPB : 1;
+    int cap = (163840 / blocks_per_cu - tg.tab_entries * 8 - 32 * LUTR_T2_WPB) / (node * LUTR_T2_WPB);
+    if (const char *e = getenv("LUTR_WIN_NODES")) { const int c = atoi(e); if (c >= 64 && c < cap) cap = c; }
+    if (cap < 128) return nullptr;
+    tg.win_nodes = cap;
+    tg.queue = queue; tg.stats = stats;
+    const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
+    const dim3 grid((waves + LUTR_T2_WPB - 1) / LUTR_T2_WPB), block(64 * LUTR_T2_WPB);
+    if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_T2_WPB), 1, st) != hipSuccess) return nullptr;
+    const size_t lds = (size_t)tg.tab_entries * 8 + 32 * LUTR_T2_WPB + (size_t)LUTR_T2_WPB * tg.win_nodes * node;
+    Planes2 TP;
+    for (int i = 0; i < 3; i++) {
+        TP.s[i] = P.s[i]; TP.d[i] = P.d[i];
+        TP.ss[i] = (unsigned)P.ss[i]; TP.ds[i] = (unsigned)P.ds[i];
+        TP.sfs[i] = (unsigned long long)P.sfs[i]; TP.dfs[i] = (unsigned long long)P.dfs[i];
+    }
+    if (getenv("LUTR_DEBUG"))
+        fprintf(stderr, "[lutr t2] nsx %d nry %d chunk %d chunks %d blocks %u lds/block %zu win_nodes %d tab %d variant %d\n",
+                tg.nsx, tg.nry, tg.ch, tg.nchunks, grid.x, lds, tg.win_nodes, tg.tab_entries, vv);
+
+#define T2_LAUNCH(WI, WO, X, Y, I, PR, VV, NAME) \
+    do { \
+        auto kern = k_yuv_tile2<WI, WO, X, Y, I, PR, VV>; \
+        allow_lds((const void *)kern, lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, L, K, TP, G, tg); \
+        return NAME; \
+    } while (0)
+#define T2_NAME(WI, WO, X, Y, I, SUF) "k_yuv_tile2<" #WI #WO "," #X #Y "," #I SUF ">"
+#define T2_CASE(WI, WO, X, Y, I) \
+    if (mode == I) { \
+        if (I != LUTR_INTERP_NEAREST) { \
+            if (pre && vv == V_FAST) T2_LAUNCH(WI, WO, X, Y, (I == 0 ? 2 : I), 1, V_FAST, T2_NAME(WI, WO, X, Y, I, ",pre,tab,unit,fast")); \
+            if (pre) T2_LAUNCH(WI, WO, X, Y, (I == 0 ? 2 : I), 1, V_UNIT, T2_NAME(WI, WO, X, Y, I, ",pre,tab,unit")); \
+            if (vv == V_FAST) T2_LAUNCH(WI, WO, X, Y, (I == 0 ? 2 : I), 0, V_FAST, T2_NAME(WI, WO, X, Y, I, ",tab,unit,fast")); \
+        } \
+        if (vv == V_UNIT) T2_LAUNCH(WI, WO, X, Y, I, 0, V_UNIT, T2_NAME(WI, WO, X, Y, I, ",tab,unit")); \
+        if (vv == V_TAB) T2_LAUNCH(WI, WO, X, Y, I, 0, V_TAB, T2_NAME(WI, WO, X, Y, I, ",tab")); \
+        T2_LAUNCH(WI, WO, X, Y, I, 0, V_GEN, T2_NAME(WI, WO, X, Y, I, "")); \
+    }
+#if LUTR_T2_ONLY
+    T2_CASE(LUTR_T2_WI, LUTR_T2_WO, LUTR_T2_X, LUTR_T2_Y, 2)
+#else
+    T2_CASE(LUTR_T2_WI, LUTR_T2_WO, LUTR_T2_X, LUTR_T2_Y, 0)
+    T2_CASE(LUTR_T2_WI, LUTR_T2_WO, LUTR_T2_X, LUTR_T2_Y, 1)
+    T2_CASE(LUTR_T2_WI, LUTR_T2_WO, LUTR_T2_X, LUTR_T2_Y, 2)
+#endif
+    return nullptr;
+}
+
+}  // namespace lutr

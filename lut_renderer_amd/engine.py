@@ -194,6 +194,11 @@ class LutEngine:
     def set_variant(self, name: str) -> None:
         _native.check(self._lib.lutr_ctx_set_variant(self._ctx, _native.VARIANT[name]))
 
+    def set_precision(self, name: str) -> None:
+        """"strict" (default): bit-exact with FFmpeg's scalar C.  "fast": allow the tolerance-bounded tile kernels
+        (<= 1 code from strict at 8 and 10 bit; include/lutr.h lutr_ctx_set_precision)."""
+        _native.check(self._lib.lutr_ctx_set_precision(self._ctx, _native.PRECISION[name]))
+
     @property
     def last_kernel(self) -> str:
         return self._lib.lutr_ctx_last_kernel(self._ctx).decode()
@@ -203,7 +208,7 @@ class LutEngine:
         out = (C.c_uint64 * 8)()
         _native.check(self._lib.lutr_ctx_tile_stats(self._ctx, int(enable), out))
         return {"tiles": out[0], "misses": out[1], "global_tiles": out[2], "staged": out[3],
-                "clock_mhz": out[4], "max_wave_us": out[5], "sum_wave_us": out[6]}
+                "clock_mhz": out[4], "max_wave_us": out[5], "sum_wave_us": out[6], "level2_tiles": out[7]}
 
     def sync(self) -> None:
         _native.check(self._lib.lutr_ctx_sync(self._ctx))

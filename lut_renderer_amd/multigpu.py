@@ -84,6 +84,10 @@ class LutEngineGroup:
         for e in self.engines:
             e.set_variant(name)
 
+    def set_precision(self, name: str) -> None:
+        for e in self.engines:
+            e.set_precision(name)
+
     @property
     def last_kernels(self) -> List[str]:
         return [e.last_kernel for e in self.engines]

@@ -75,6 +75,11 @@ def load() -> C.CDLL:
         lib.orc_apply_yuv.argtypes = [C.POINTER(OrcLut), C.c_int, C.POINTER(YuvConsts)] + [C.c_int] * 7 + \
                                      [P3, S3, P3, S3, C.c_int]
         lib.orc_apply_yuv_dither.argtypes = lib.orc_apply_yuv.argtypes
+        lib.orc_apply_yuv_fast.argtypes = lib.orc_apply_yuv.argtypes
+        lib.orc_f2h.argtypes = [C.c_float]
+        lib.orc_f2h.restype = C.c_uint16
+        lib.orc_h2f.argtypes = [C.c_uint16]
+        lib.orc_h2f.restype = C.c_float
         lib.orc_dither_plane.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
                                          C.c_ssize_t]
         lib.orc_dither_plane.restype = None
@@ -184,11 +189,14 @@ def yuv_constants(matrix_in="bt709", range_in="tv", matrix_out=None, range_out="
 
 
 def apply_yuv(table, scale, interp: str, consts: YuvConsts, din: int, dl: int, dout: int,
-              csx: int, csy: int, planes, nthreads: int = 1, dither: str = "none"):
+              csx: int, csy: int, planes, nthreads: int = 1, dither: str = "none", fast: bool = False):
     """planes: (Y, Cb, Cr) arrays; returns new (Y, Cb, Cr) with the output container dtype.
-    dither="error_diffusion": Floyd-Steinberg on the final quantisation (orc_apply_yuv_dither)."""
+    dither="error_diffusion": Floyd-Steinberg on the final quantisation (orc_apply_yuv_dither).
+    fast=True: the product's tolerance-bounded FAST variant (orc_apply_yuv_fast), not FFmpeg's arithmetic."""
     if dither not in ("none", "error_diffusion"):
         raise ValueError(dither)
+    if fast and dither != "none":
+        raise ValueError("the fast variant has no dither path")
     lut, _keep = _lut_struct(table, scale)
     src = [np.ascontiguousarray(p) for p in planes]
     odt = np.uint8 if dout <= 8 else np.uint16
@@ -196,7 +204,7 @@ def apply_yuv(table, scale, interp: str, consts: YuvConsts, din: int, dl: int, d
     h, w = src[0].shape
     sp, ss = _plane_args(src)
     dp, ds = _plane_args(dst)
-    fn = load().orc_apply_yuv if dither == "none" else load().orc_apply_yuv_dither
+    fn = load().orc_apply_yuv_fast if fast else (load().orc_apply_yuv if dither == "none" else load().orc_apply_yuv_dither)
     rc = fn(C.byref(lut), INTERP[interp], C.byref(consts), din, dl, dout, csx, csy, w, h, sp, ss, dp, ds, nthreads)
     if rc:
         raise OracleError(rc)

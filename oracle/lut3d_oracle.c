@@ -810,7 +810,129 @@ typedef struct {
     uint8_t *dst[3]; ptrdiff_t ds[3];
     lut_consts lk;
     float *fdst[3]; int fw[3];      /* dither path: unquantised output planes (values before the +0.5 / floor) */
+    const uint16_t *lat16;          /* fast variant: nodes as fp16 of value * M, [r][g][b][3]; NULL = strict */
 } yuv_job;
+
+/* ------------------------------------------------------------------ */
+/* FAST variant (lutr_ctx_set_precision(FAST), csrc/lutr_tile2.hip V_FAST): the same pixel pipeline with two      */
+/* changes -- lattice nodes are fp16 of value * (2^depth - 1) (round to nearest even), and the blend is a fused    */
+/* multiply-add chain with fp32 accumulation in the kernels' order.  Coordinates, truncation and the YUV contract  */
+/* are the strict ones.  This restatement lets the GPU be checked bit for bit; tests bound |fast - strict| <= 1.   */
+/* ------------------------------------------------------------------ */
+static uint16_t f2h_rne(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));   /* inf / nan */
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                       /* rounds to inf */
+    if (x < 0x33000001u) return (uint16_t)sign;                                                     /* rounds to zero */
+    if (x < 0x38800000u) {                                   /* subnormal half: value * 2^24 rounded to an integer */
+        const int e = (int)(x >> 23);                        /* biased float exponent, 102..112 */
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;      /* 24-bit significand */
+        const int sh = 126 - e;                              /* bits to drop: 14..24 */
+        uint32_t h = m >> sh;
+        const uint32_t rem = m & ((1u << sh) - 1), half = 1u << (sh - 1);
+        if (rem > half || (rem == half && (h & 1))) h++;
+        return (uint16_t)(sign | h);
+    }
+    {
+        uint32_t h = ((x - 0x38000000u) >> 13);              /* rebias exponent, keep 10 fraction bits */
+        const uint32_t rem = x & 0x1fffu;
+        if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+        return (uint16_t)(sign | h);
+    }
+}
+
+static float h2f(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+    float f;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { f = (float)m * (1.0f / 16777216.0f); memcpy(&x, &f, 4); x |= sign; }     /* m * 2^-24, exact */
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+uint16_t orc_f2h(float f) { return f2h_rne(f); }
+float orc_h2f(uint16_t h) { return h2f(h); }
+
+static inline rgbvec node16(const uint16_t *l16, int n, int r, int g, int b)
+{
+    const uint16_t *p = &l16[(((size_t)r * n + g) * n + b) * 3];
+    rgbvec v = {h2f(p[0]), h2f(p[1]), h2f(p[2])};
+    return v;
+}
+
+static inline float med3f(float a, float b, float c)
+{
+    const float lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+}
+
+/* one pixel of the fast variant; returns codes before the YUV side */
+static inline void lut_pixel_fast(const uint16_t *l16, int n, int mode, const lut_consts *k,
+                                  int r, int g, int b, int *ro, int *go, int *bo)
+{
+    const rgbvec rgb = {(float)r * k->scale_f, (float)g * k->scale_f, (float)b * k->scale_f};
+    const rgbvec s = {clipf(rgb.r * k->scale_c[0], 0, k->lut_max), clipf(rgb.g * k->scale_c[1], 0, k->lut_max),
+                      clipf(rgb.b * k->scale_c[2], 0, k->lut_max)};
+    rgbvec v;
+    if (mode == ORC_NEAREST) {
+        v = node16(l16, n, NEAR(s.r), NEAR(s.g), NEAR(s.b));
+    } else {
+        const int p[3] = {PREV(s.r), PREV(s.g), PREV(s.b)};
+        const int x[3] = {NEXT(s.r, n), NEXT(s.g, n), NEXT(s.b, n)};
+        const float dr = s.r - p[0], dg = s.g - p[1], db = s.b - p[2];
+        if (mode == ORC_TRILINEAR) {
+            const rgbvec c000 = node16(l16, n, p[0], p[1], p[2]), c001 = node16(l16, n, p[0], p[1], x[2]);
+            const rgbvec c010 = node16(l16, n, p[0], x[1], p[2]), c011 = node16(l16, n, p[0], x[1], x[2]);
+            const rgbvec c100 = node16(l16, n, x[0], p[1], p[2]), c101 = node16(l16, n, x[0], p[1], x[2]);
+            const rgbvec c110 = node16(l16, n, x[0], x[1], p[2]), c111 = node16(l16, n, x[0], x[1], x[2]);
+#define FL(a, b, f) fmaf((b) - (a), (f), (a))
+#define TRI16(ch) \
+            { \
+                const float c00 = FL(c000.ch, c100.ch, dr), c10 = FL(c010.ch, c110.ch, dr); \
+                const float c01 = FL(c001.ch, c101.ch, dr), c11 = FL(c011.ch, c111.ch, dr); \
+                const float c0 = FL(c00, c10, dg), c1 = FL(c01, c11, dg); \
+                v.ch = FL(c0, c1, db); \
+            }
+            TRI16(r) TRI16(g) TRI16(b)
+#undef TRI16
+#undef FL
+        } else {
+            /* the kernels' sorted form: (1-x) c000 + (x-y) cA + (y-z) cB + z c111, cA one step along the axis of the
+             * largest fraction, cB all steps but the one along the smallest */
+            const float mx = fmaxf(fmaxf(dr, dg), db), md = med3f(dr, dg, db), mn = fminf(fminf(dr, dg), db);
+            const int rg = dr > dg, gb = dg > db, rb = dr > db;
+            const int amax = (rg && rb) ? 0 : (gb ? 1 : 2);
+            const int amin = (gb && rb) ? 2 : (rg ? 1 : 0);
+            int a[3] = {p[0], p[1], p[2]}, bq[3] = {x[0], x[1], x[2]};
+            a[amax] = x[amax];
+            bq[amin] = p[amin];
+            const rgbvec c0 = node16(l16, n, p[0], p[1], p[2]), c1 = node16(l16, n, a[0], a[1], a[2]);
+            const rgbvec c2 = node16(l16, n, bq[0], bq[1], bq[2]), c3 = node16(l16, n, x[0], x[1], x[2]);
+            const float w0 = 1.0f - mx, w1 = mx - md, w2 = md - mn, w3 = mn;
+            v.r = fmaf(w3, c3.r, fmaf(w2, c2.r, fmaf(w1, c1.r, w0 * c0.r)));
+            v.g = fmaf(w3, c3.g, fmaf(w2, c2.g, fmaf(w1, c1.g, w0 * c0.g)));
+            v.b = fmaf(w3, c3.b, fmaf(w2, c2.b, fmaf(w1, c1.b, w0 * c0.b)));
+        }
+    }
+    /* nodes are already scaled by M: truncate, clip */
+    {
+        const float t[3] = {truncf(v.r), truncf(v.g), truncf(v.b)};
+        int *o[3] = {ro, go, bo};
+        for (int c = 0; c < 3; c++) {
+            int i = t[c] >= 2147483648.0f ? INT32_MAX : (t[c] > -2147483648.0f ? (int)t[c] : INT32_MIN);
+            *o[c] = i < 0 ? 0 : (i > k->maxi ? k->maxi : i);
+        }
+    }
+}
+
 
 static inline float clip_floor(float v, float hi)
 {
@@ -852,8 +974,11 @@ static void yuv_slice(void *arg, int y0, int y1)
                     const float rf = clip_floor(yy + rv, k->max_l);
                     const float gf = clip_floor(yy + gv, k->max_l);
                     const float bf = clip_floor(yy + bu, k->max_l);
-                    lut_pixel(j->lut, j->mode, j->lk.scale_f, j->lk.scale_c, j->lk.lut_max,
-                              j->lk.maxf, j->lk.maxi, (int)rf, (int)gf, (int)bf, &ro, &go, &bo);
+                    if (j->lat16)
+                        lut_pixel_fast(j->lat16, j->lut->n, j->mode, &j->lk, (int)rf, (int)gf, (int)bf, &ro, &go, &bo);
+                    else
+                        lut_pixel(j->lut, j->mode, j->lk.scale_f, j->lk.scale_c, j->lk.lut_max,
+                                  j->lk.maxf, j->lk.maxi, (int)rf, (int)gf, (int)bf, &ro, &go, &bo);
                     rs += (float)ro; gs += (float)go; bs += (float)bo;
                     if (by + dy < j->h && bx + dx < j->w) {
                         const float yf = fmaf(k->cyr, (float)ro, fmaf(k->cyg, (float)go, fmaf(k->cyb, (float)bo, k->yob)));
@@ -898,8 +1023,40 @@ int orc_apply_yuv(const orc_lut *lut, int mode, const orc_yuv_consts *k,
         j.dst[c] = (uint8_t *)dst[c]; j.ds[c] = dstride[c];
         j.fdst[c] = NULL; j.fw[c] = 0;
     }
+    j.lat16 = NULL;
     make_lut_consts(lut, dl, &j.lk);
     run_slices(yuv_slice, &j, h, 1 << csy, nthreads);
+    return 0;
+}
+
+int orc_apply_yuv_fast(const orc_lut *lut, int mode, const orc_yuv_consts *k,
+                       int din, int dl, int dout, int csx, int csy, int w, int h,
+                       const void *const src[3], const ptrdiff_t sstride[3],
+                       void *const dst[3], const ptrdiff_t dstride[3], int nthreads)
+{
+    yuv_job j;
+    if (!lut || !lut->rgb || !k || w < 0 || h < 0 || csx < 0 || csx > 1 || csy < 0 || csy > 1 ||
+        din < 8 || din > 16 || (dl != 8 && dl != 10) || dout < 8 || dout > 16 ||
+        mode < ORC_NEAREST || mode > ORC_TETRAHEDRAL)
+        return ORC_EINVAL;
+    if (w == 0 || h == 0)
+        return 0;
+    const size_t count = (size_t)lut->n * lut->n * lut->n * 3;
+    uint16_t *l16 = (uint16_t *)malloc(count * sizeof(uint16_t));
+    if (!l16) return ORC_ENOMEM;
+    const float m = (float)((1 << dl) - 1);
+    for (size_t i = 0; i < count; i++) l16[i] = f2h_rne(lut->rgb[i] * m);
+    j.lut = lut; j.mode = mode; j.k = k;
+    j.din = din; j.dl = dl; j.dout = dout; j.csx = csx; j.csy = csy; j.w = w; j.h = h;
+    for (int c = 0; c < 3; c++) {
+        j.src[c] = (const uint8_t *)src[c]; j.ss[c] = sstride[c];
+        j.dst[c] = (uint8_t *)dst[c]; j.ds[c] = dstride[c];
+        j.fdst[c] = NULL; j.fw[c] = 0;
+    }
+    j.lat16 = l16;
+    make_lut_consts(lut, dl, &j.lk);
+    run_slices(yuv_slice, &j, h, 1 << csy, nthreads);
+    free(l16);
     return 0;
 }
 
@@ -965,6 +1122,7 @@ int orc_apply_yuv_dither(const orc_lut *lut, int mode, const orc_yuv_consts *k,
             return ORC_ENOMEM;
         }
     }
+    j.lat16 = NULL;
     make_lut_consts(lut, dl, &j.lk);
     run_slices(yuv_slice, &j, h, 1 << csy, nthreads);
     for (int c = 0; c < 3; c++) {

@@ -97,6 +97,17 @@ int orc_apply_yuv(const orc_lut *lut, int interp, const orc_yuv_consts *k,
 /* the same path with error-diffusion dither on the final quantisation (reference ffmpeg.py:305-307,
  * `zscale=dither=error_diffusion`); whole frames only.  orc_dither_plane is the Floyd-Steinberg step
  * alone: x = w*h unquantised values, dst = integer plane (uint8, or uint16 when wide). */
+/* The FAST variant of the product (include/lutr.h lutr_ctx_set_precision): nodes as fp16 of value * (2^dl - 1), blend as
+ * an fmaf chain with fp32 accumulation in the kernels' order; everything else as orc_apply_yuv.  dl must be 8 or 10,
+ * interp nearest / trilinear / tetrahedral.  Bit-exact twin of csrc/lutr_tile2.hip V_FAST. */
+int orc_apply_yuv_fast(const orc_lut *lut, int interp, const orc_yuv_consts *k,
+                       int din, int dl, int dout, int csx, int csy, int w, int h,
+                       const void *const src[3], const ptrdiff_t sstride[3],
+                       void *const dst[3], const ptrdiff_t dstride[3], int nthreads);
+/* fp32 <-> fp16 (round to nearest even) as used for the fast lattice */
+uint16_t orc_f2h(float f);
+float orc_h2f(uint16_t h);
+
 int orc_apply_yuv_dither(const orc_lut *lut, int mode, const orc_yuv_consts *k,
                          int din, int dl, int dout, int csx, int csy, int w, int h,
                          const void *const src[3], const ptrdiff_t sstride[3],
