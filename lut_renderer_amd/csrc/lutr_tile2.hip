@@ -107,6 +107,8 @@ struct Geom {
     int win_nodes;        // LDS window capacity per wave, in nodes
     int tab_entries;      // per-code coordinate table at LDS offset 0 (0 = coordinates are computed)
     int max_raw;          // 2^din - 1: a raw code above it cannot be trusted to stay inside the table
+    int whole;            // 1: the WHOLE lattice fits the workgroup's LDS (N <= 21 strict / 25 fast at 10 bit): staged once
+                          // per workgroup, shared by its waves, no windows, no validity tests -- content cannot matter
     unsigned *queue;      // device counter, set by the launcher before every launch
     unsigned *stats;      // optional device counters; nullptr = off
 };
@@ -897,7 +899,20 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         if constexpr (LUTR_T2_PIN >= 2) { K.ky = in_vgpr(K_.ky); K.yb = in_vgpr(K_.yb); K.yob = in_vgpr(K_.yob); }
         if constexpr (!N::fast) L.maxf = in_vgpr(L_.maxf);
     }
-    if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier
+    if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier ...
+    if (TG.whole) {                                                             // ... but for this one, in whole-lattice mode
+        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 32;
+        const int nodes = L.n1 * L.n1 * L.n1;
+        for (int i = threadIdx.x; i < nodes; i += 64 * LUTR_T2_WPB) {
+            if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[i];
+            else {
+                const float4 v = L.lat[i];
+                if constexpr (N::lds == 16) ((float4 *)dst)[i] = v;
+                else { float *q = (float *)(dst + 12 * i); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
+            }
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int tab_bytes = TG.tab_entries * 8;
@@ -914,6 +929,12 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     W.fr = W.fg = W.fb = W.fc = 0.0f; W.o_r = W.o_g = 0;
     // empty box: lo > hi in every plane, so the first tile always restages
     W.ylo = W.cblo = W.crlo = 0xffffffffu; W.yhi = W.cbhi = W.crhi = 0u;
+    if (TG.whole) {
+        // lattice layout of the global copy ((N+1)^3 nodes, blue fastest, index N replicates N-1): prev + 1 is always staged
+        W.o_r = N::lds * L.n1 * L.n1; W.o_g = N::lds * L.n1;
+        W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)N::lds;
+        W.fc = (float)(lds_base() + tab_bytes + LUTR_T2_WPB * 32);
+    }
     constexpr int YIB = T::YWI * 4, YOB = T::YWO * 4, CIB = T::CWI * 4, COB = T::CWO * 4;
 
     // Input words of a tile.  Idle lanes of edge tiles re-read a valid unit of the same tile.
@@ -970,7 +991,11 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         bool use_lds = box_holds(W, e);                       // first level: raw extremes against the window's raw box
         if (LUTR_T2_EXP >= 1 && have_win) use_lds = true;
         TK(tk_head)
-        if (!use_lds) {
+        if (TG.whole) {
+            // every cell is in LDS; only raw codes above 2^din - 1 (which the padded table does not cover) need the clamping body
+            const uint32_t top = pack_hi<WIN>(TG.max_raw);
+            use_lds = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
+        } else if (!use_lds) {
             st_level2++;
 
             const Bnd bn = tile_bounds<WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, TG, in);
@@ -1126,6 +1151,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         const double eff = ((double)uw / (((uw + lw - 1) / lw) * lw)) * ((double)urows / (((urows + lh - 1) / lh) * lh));
         if (eff > best_eff + 0.02) { best_eff = eff; best = l; }
     }
+    if (const char *e = getenv("LUTR_LW_LOG2")) { const int c = atoi(e); if (c >= 2 && c <= 6) best = c; }
     tg.lw_log2 = best; tg.uw = uw; tg.urows = urows;
     tg.nsx = (uw + (1 << best) - 1) >> best;
     tg.nry = (urows + (64 >> best) - 1) / (64 >> best);
@@ -1142,13 +1168,18 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     const int blocks_per_cu = waves_per_cu / LUTR_T2_WPB > 0 ? waves_per_cu / LUTR_T2_WPB : 1;
     int cap = (163840 / blocks_per_cu - tg.tab_entries * 8 - 32 * LUTR_T2_WPB) / (node * LUTR_T2_WPB);
     if (const char *e = getenv("LUTR_WIN_NODES")) { const int c = atoi(e); if (c >= 64 && c < cap) cap = c; }
-    if (cap < 128) return nullptr;
-    tg.win_nodes = cap;
+    // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS
+    const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
+    tg.whole = (blocks_per_cu == 1 && !getenv("LUTR_NO_WHOLE") &&
+                tg.tab_entries * 8 + 32 * LUTR_T2_WPB + whole_bytes <= 163840) ? 1 : 0;
+    if (!tg.whole && cap < 128) return nullptr;
+    tg.win_nodes = tg.whole ? 0 : cap;
     tg.queue = queue; tg.stats = stats;
     const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
     const dim3 grid((waves + LUTR_T2_WPB - 1) / LUTR_T2_WPB), block(64 * LUTR_T2_WPB);
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_T2_WPB), 1, st) != hipSuccess) return nullptr;
-    const size_t lds = (size_t)tg.tab_entries * 8 + 32 * LUTR_T2_WPB + (size_t)LUTR_T2_WPB * tg.win_nodes * node;
+    const size_t lds = (size_t)tg.tab_entries * 8 + 32 * LUTR_T2_WPB +
+                       (tg.whole ? (size_t)whole_bytes : (size_t)LUTR_T2_WPB * tg.win_nodes * node);
     Planes2 TP;
     for (int i = 0; i < 3; i++) {
         TP.s[i] = P.s[i]; TP.d[i] = P.d[i];
@@ -1164,7 +1195,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         auto kern = k_yuv_tile2<WI, WO, X, Y, I, PR, VV>; \
         allow_lds((const void *)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, st, L, K, TP, G, tg); \
-        return NAME; \
+        return tg.whole ? NAME "+whole-lattice" : NAME; \
     } while (0)
 #define T2_NAME(WI, WO, X, Y, I, SUF) "k_yuv_tile2<" #WI #WO "," #X #Y "," #I SUF ">"
 #define T2_CASE(WI, WO, X, Y, I) \

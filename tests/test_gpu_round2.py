@@ -329,3 +329,42 @@ def test_cli_stops_on_sigterm_with_whole_frames_written(cube_dir, tmp_path):
     assert proc.returncode == 255, out[-2000:]
     assert "Duration: 00:02:40.00" in out and "received signal 15" in out
     assert 0 < got["bytes"] < fb * nframes and got["bytes"] % fb == 0
+
+
+# ------------------------------------------------------------------ whole lattice in LDS (small N)
+@pytest.mark.parametrize("n,precision,expect_whole", [(17, "strict", True), (17, "fast", True), (21, "strict", True),
+                                                        (25, "fast", True), (25, "strict", False), (33, "fast", False)])
+def test_small_lattices_are_staged_whole_and_content_stops_mattering(engine, orc, n, precision, expect_whole):
+    """A lattice that fits one workgroup's LDS beside the coordinate table (N <= 21 strict, N <= 25 fast at 10 bit; .3dl files
+    are always 17^3) is staged once per workgroup: no windows, no validity tests, so uniform-random frames -- the worst case
+    of the window kernels -- take exactly the same path as natural ones."""
+    lat = cube.log709_lattice(n)
+    one = np.ones(3, np.float32)
+    engine.set_lut(cube.CubeLut(n, one, lat))
+    engine.set_variant("vec_lds")
+    engine.set_precision(precision)
+    try:
+        k = orc.yuv_constants(din=10)
+        for dist in ("uniform", "natural"):
+            src = frames.make_yuv(dist, 256, 72, 10, 1, 1, k=51)
+            for mode in ("tetrahedral", "trilinear"):
+                engine.tile_stats(True)
+                got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le", interp=mode)
+                st = engine.tile_stats(False)
+                whole = "whole-lattice" in engine.last_kernel
+                if mode == "tetrahedral":
+                    assert whole == expect_whole, (engine.last_kernel, n, precision)
+                if whole:
+                    assert st["global_tiles"] == 0 and st["misses"] == 0 and st["staged"] == 0
+                want = orc.apply_yuv(lat, one, mode, k, 10, 10, 10, 1, 1, src, fast="fast" in engine.last_kernel)
+                _assert_equal(_to_np(got, np.uint16), want, f"whole {n} {precision} {dist} {mode}")
+        # raw codes above 2^10 - 1 in the 16-bit containers: the table does not cover them, the clamping body takes the tile
+        src = frames.make_yuv("uniform", 256, 72, 10, 1, 1, k=52)
+        src[0][5, 7] = 60000
+        src[1][3, 3] = 2047
+        got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le")
+        want = orc.apply_yuv(lat, one, "tetrahedral", k, 10, 10, 10, 1, 1, src, fast="fast" in engine.last_kernel)
+        _assert_equal(_to_np(got, np.uint16), want, f"whole {n} {precision} wild codes")
+    finally:
+        engine.set_precision("strict")
+        engine.set_variant("auto")
