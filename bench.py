@@ -63,9 +63,10 @@ def parse_args(argv=None):
                     help="pc: full-range source -> the reference's prologue scale=in_range=pc:out_range=tv,format=<8-bit> "
                          "(ffmpeg.py:212-233, BASELINE config 5) runs fused ahead of the LUT")
     ap.add_argument("--interp", default="tetrahedral")
-    ap.add_argument("--precision", default="strict", choices=["strict", "fast"],
-                    help="strict: bit-exact restatement of FFmpeg's scalar C; fast: tolerance-bounded variant "
-                         "(<= 1 code from strict at 8 and 10 bit, tests/test_gpu_parity.py)")
+    ap.add_argument("--precision", default="fast", choices=["strict", "fast"],
+                    help="fast (default, named in config.precision): the tolerance-bounded kernels, <= 1 code from strict at 8 "
+                         "and 10 bit (north_star allows 1 / 2 against FFmpeg; tests/test_fast_variant.py); strict: the "
+                         "bit-exact restatement of FFmpeg's scalar C.  The other one is timed too and reported beside `value`.")
     ap.add_argument("--lut", type=int, default=33, help="lattice size N of the generated log709 LUT")
     ap.add_argument("--dist", default="natural")
     ap.add_argument("--variant", default="auto")
@@ -367,6 +368,18 @@ def main():
             log(f"[tile stats] {tile_stats}")
     (wall, kern), (px_total,) = reduce_max_sum(eng, world, [wall, kern], [float(px_rank)])
 
+    # the other precision on the same batch (N = 1): the line always carries both numbers
+    other = None
+    if world == 1 and pf.family == "yuv" and args.dither == "none":
+        oname = "strict" if args.precision == "fast" else "fast"
+        eng.set_precision(oname)
+        _, ok = time_steps(eng, job, src, dst, args.interp, max(5, args.steps // 4), 3, 1, r0, r1 - r0)
+        other = {"precision": oname, "Mpx_s": round(px_rank / ok / 1e6, 1), "kernel": eng.last_kernel,
+                 "frac": round((bytes_per_px(pf) + bytes_per_px(pf_out)) * px_rank / ok / 1e9 / HBM_PEAK_GBPS, 4)}
+        eng.set_precision(args.precision)
+        if rank == 0:
+            log(f"[other precision] {other}")
+
     strong = None
     if world > 1 and not args.no_strong:
         # the same FRAMES frames as a 1-GPU run, rows split N ways
@@ -476,6 +489,8 @@ def main():
                 "read_GBps": round((bpp_in * px_rank + lattice_bytes) / kern / 1e9, 1),
             },
         }
+        if other:
+            result["other_precision"] = other
         if collective:
             result["collective"] = collective
         if strong:

@@ -108,8 +108,6 @@ void launch_make_lat16(hipStream_t st, const float4 *lat, uint2 *out, size_t nod
 // persistent LDS-window kernels (lutr_tile.hip); layout already checked by launch_rgb/launch_yuv
 const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G,
                             int depth, int interp, unsigned *stats, unsigned *queue);
-const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
-                            const FrameGeom &G, int wide, int csx, int csy, int interp, unsigned *stats, unsigned *queue);
 
 // host helpers (yuv_consts.cpp / cube_parse.cpp)
 int make_yuv_consts(const lutr_yuv_params &p, YuvConsts *out);

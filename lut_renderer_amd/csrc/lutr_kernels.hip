@@ -326,6 +326,7 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     const int bh = 1 << csy;
     if (variant == VAR_VEC_LDS || (variant == VAR_AUTO && !small_job((long long)G.w * G.rows * G.nframes))) {
         if (const char *name = try_tile2(st, L, K, P, G, din, dout, lut_depth, csx, csy, mode, fast, stats, queue)) return name;
+        if (variant == VAR_VEC_LDS) return nullptr;          // asked for the tile kernels, and they cannot take this call
     }
     const long long cbytes = (long long)(pxt >> csx) * (win ? 2 : 1);      // chroma bytes per thread
     bool vec_ok = (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
@@ -335,29 +336,23 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     if (vec_ok) vec_ok = planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, cbytes, G.nframes > 1) &&
                          planes_aligned(P, 2, cbytes, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
-    if (vec_ok && ((variant == VAR_AUTO && !small_job((long long)G.w * G.rows * G.nframes)) || variant == VAR_VEC_LDS))
-        return launch_yuv_tile(st, L, K, P, G, win, csx, csy, mode, stats, queue);
-    // ragged width on aligned (padded) rows: fast kernel up to the last whole unit, scalar kernel for the rest
+    // ragged width on aligned (padded) rows: tile kernel up to the last whole unit, scalar kernel for the rest
     // (the split falls on a chroma-block boundary: the unit is 8 or 16 luma samples wide)
     const int wv = G.w / pxt * pxt;
-    if (variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w && !small_job((long long)G.w * G.rows * G.nframes) &&
-        (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
-        win == wout && G.row0 % bh == 0 && G.rows % bh == 0 && !(csx == 0 && csy == 1) &&
-        (long long)(wv / pxt) * (G.rows >> csy) * G.nframes < 0x7fffffffll &&
-        planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, cbytes, G.nframes > 1) &&
-        planes_aligned(P, 2, cbytes, G.nframes > 1)) {
+    if (variant == VAR_AUTO && wv > 0 && wv < G.w && !small_job((long long)G.w * G.rows * G.nframes)) {
         FrameGeom Gv = G, Ge = G;
         Gv.w = wv;
         Ge.w = G.w - wv;
-        PlaneSet Pe = P;
-        const long long bs = win ? 2 : 1;
-        Pe.s[0] += wv * bs; Pe.d[0] += wv * bs;
-        for (int c = 1; c < 3; c++) { Pe.s[c] += (wv >> csx) * bs; Pe.d[c] += (wv >> csx) * bs; }
-        const char *name = launch_yuv_tile(st, L, K, P, Gv, win, csx, csy, mode, stats, queue);
-        const long long eb = (long long)((Ge.w + (1 << csx) - 1) >> csx) * ((G.rows + bh - 1) >> csy) * G.nframes;
-        hipLaunchKernelGGL(k_yuv_generic, dim3(grid_for(eb, 256 * 64)), dim3(256), 0, st, L, K, Pe, Ge, win, wout,
-                           csx, csy, mode);
-        return name;
+        if (const char *name = try_tile2(st, L, K, P, Gv, din, dout, lut_depth, csx, csy, mode, fast, stats, queue)) {
+            PlaneSet Pe = P;
+            const long long bsi = win ? 2 : 1, bso = wout ? 2 : 1;
+            Pe.s[0] += wv * bsi; Pe.d[0] += wv * bso;
+            for (int c = 1; c < 3; c++) { Pe.s[c] += (wv >> csx) * bsi; Pe.d[c] += (wv >> csx) * bso; }
+            const long long eb = (long long)((Ge.w + (1 << csx) - 1) >> csx) * ((G.rows + bh - 1) >> csy) * G.nframes;
+            hipLaunchKernelGGL(k_yuv_generic, dim3(grid_for(eb, 256 * 64)), dim3(256), 0, st, L, K, Pe, Ge, win, wout,
+                               csx, csy, mode);
+            return name;
+        }
     }
     // 10-bit (or deeper) source written as 8 bit: the vector kernel with 16-byte luma units
     if (!vec_ok && variant != VAR_GENERIC && win == 1 && wout == 0 &&

@@ -1,7 +1,9 @@
-// lutr_tile.hip -- the fast path: persistent waves with a per-wave LDS lattice window.
+// lutr_tile.hip -- planar RGB (gbrp*) on persistent waves with a per-wave LDS lattice window: the round-1 design, kept for the
+// planar-RGB formats.  The fused YUV kernels moved to lutr_tile2.hip in round 2 (raw-code-space validity instead of the
+// optimistic pass described below).
 //
-// Replaces the slice-threaded per-row loops of FFmpeg's lut3d + the scalers around it
-// (the filters /root/reference/src/lut_renderer/ffmpeg.py:212-247,:304-310 emits).
+// Replaces the slice-threaded per-row loops of FFmpeg's lut3d
+// (the filter /root/reference/src/lut_renderer/ffmpeg.py:246 emits) when the frames are planar RGB.
 //
 // Design (DESIGN.md "Kernels"):
 //   * A 33^3 fp32 lattice (431 KB; 629 KB as padded float4) does not fit the 160 KB LDS,
@@ -495,20 +497,6 @@ __device__ __forceinline__ void fence_words(uint32_t *w)
     else if constexpr (N == 8) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
 }
 
-__device__ __forceinline__ float cfloor(float v, float hi) { return tmed3(floorf(v), 0.0f, hi); }
-// RGB -> YUV side: Y and chroma are positive-offset convex mixes of codes in [0, M], so they cannot go
-// below 0; only full-range chroma can reach M+1 (128.5 + 127.5 at 8 bit).  Upper bound only.
-// The float -> unsigned conversion of wput() is the floor (v_cvt_u32_f32 truncates; the values are >= 0)
-// and hi is an integer, so min(floor(v), hi) == floor(min(v, hi)): no separate v_floor_f32.
-// DEAD: the launcher evaluated the same fma chains at their maxima (out_clip_dead) and found them
-// below hi + 1, so even the upper bound cannot bind.
-template <bool DEAD>
-__device__ __forceinline__ float ofloor(float v, float hi)
-{
-    if constexpr (DEAD) return v;
-    else return fminf(v, hi);
-}
-
 // ---------------------------------------------------------------- tile geometry
 struct TileGeom {
     int lw_log2;          // lanes along x per tile row = 1 << lw_log2 (the other lanes go down)
@@ -527,7 +515,7 @@ struct TileGeom {
     unsigned *stats;      // optional device counters; nullptr = off
 };
 
-// The tile kernels' view of the planes: 32-bit row strides (launch_rgb / launch_yuv only send layouts with positive
+// The tile kernels' view of the planes: 32-bit row strides (launch_rgb only sends layouts with positive
 // strides below 2^30 here), which halves the scalar registers they occupy -- the kernels run out of SGPRs and
 // every spilled one costs a v_readlane per tile.
 struct TilePlanes {
@@ -547,149 +535,9 @@ static inline TilePlanes tile_planes(const PlaneSet &P)
     return T;
 }
 
-// ================================================================= fused YUV tile kernel
-// A unit is what one lane handles per tile: 16 bytes of luma per row (PXT samples), BH rows tall.
-#ifndef LUTR_PIN_MORE
-#define LUTR_PIN_MORE 1
-#endif
-#ifndef LUTR_PIN_CONSTS
-#define LUTR_PIN_CONSTS 1
-#endif
-template <int WIDE, int CSX, int CSY>
-struct YuvTile {
-    static constexpr int PXT = WIDE ? 8 : 16;
-    static constexpr int BH = 1 << CSY, BW = 1 << CSX;
-    static constexpr int NC = PXT >> CSX;
-    static constexpr int YW = 4;                                   // 32-bit words of luma per row
-    static constexpr int CW = NC * (WIDE ? 2 : 1) / 4;             // 32-bit words of each chroma plane
-    uint32_t y[BH][YW], cb[CW], cr[CW];
-};
-
-template <bool LDS, int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
-__device__ __forceinline__ void yuv_tile_body(const LutConsts &L, const YuvConsts &K, const Win &W,
-                                              YuvTile<WIDE, CSX, CSY> &in, YuvTile<WIDE, CSX, CSY> &out, Bnd &bn)
-{
-    // `in` is consumed: the ordering fences below run its words through volatile asm, so the caller
-    // must re-load the tile before a second pass (only after a window miss)
-    using T = YuvTile<WIDE, CSX, CSY>;
-    // a group = 4 pixels: all BH rows of GW columns; it owns NCG chroma samples
-    constexpr int GW = 4 / T::BH, NG = T::PXT / GW, NCG = (GW >> CSX) > 0 ? (GW >> CSX) : 1;
-#pragma unroll
-    for (int dy = 0; dy < T::BH; dy++)
-#pragma unroll
-        for (int k = 0; k < T::YW; k++) out.y[dy][k] = 0;
-#pragma unroll
-    for (int k = 0; k < T::CW; k++) { out.cb[k] = 0; out.cr[k] = 0; }
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        // ---- stage A: chroma terms, integer RGB, lattice coordinates, weights (4 independent pixels)
-        float rv[NCG], gv[NCG], bu[NCG];
-#pragma unroll
-        for (int c = 0; c < NCG; c++) {
-            const int j = g * NCG + c;
-            float cbv = wsample<WIDE>(in.cb, j), crv = wsample<WIDE>(in.cr, j);
-            if constexpr (PRE) {
-                cbv = cfloor(tfma(K.pc, cbv, K.pcb), K.pre_max);
-                crv = cfloor(tfma(K.pc, crv, K.pcb), K.pre_max);
-            }
-            const float cbd = cbv - K.coff, crd = crv - K.coff;
-            rv[c] = K.krv * crd; gv[c] = tfma(K.kgu, cbd, K.kgv * crd); bu[c] = K.kbu * cbd;
-        }
-        PxC pc[4];
-        Cell cell[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
-            float yv = wsample<WIDE>(in.y[dy], i);
-            if constexpr (PRE) yv = cfloor(tfma(K.py, yv, K.pyb), K.pre_max);
-            const float yy = tfma(K.ky, yv, K.yb);
-            if constexpr (TAB) {
-                // clip(floor(v), 0, M) as an integer: v_cvt_u32_f32 truncates and saturates negatives to 0
-                const unsigned mi = (unsigned)K.max_l;
-                const unsigned ri = min((unsigned)(yy + rv[c]), mi), gi = min((unsigned)(yy + gv[c]), mi),
-                               bi = min((unsigned)(yy + bu[c]), mi);
-                pc[p] = px_coords_tab<LDS, INTERP>(L, W, ri, gi, bi, cell[p]);
-            } else {
-                const float rq = cfloor(yy + rv[c], K.max_l), gq = cfloor(yy + gv[c], K.max_l), bq = cfloor(yy + bu[c], K.max_l);
-                pc[p] = px_coords<LDS, INTERP>(L, W, rq, gq, bq, cell[p]);
-            }
-            if (p & 1) bnd_update2(bn, cell[p - 1], cell[p]);
-        }
-        // ---- stage B: taps and blend (pairs keep 8 reads in flight), stage C: outputs
-        Rgb3 o[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) o[p] = px_quant<TAB == 2>(L, px_blend<LDS, INTERP>(L, W, pc[p]));
-        // chroma block sums: integer codes (exact in fp32 in any order); the first pixel of a block
-        // initialises its sum (a literal 0 + x is not foldable without fast-math and costs an add)
-        float rs[NCG], gs[NCG], bs[NCG];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
-            if (dy == 0 && ((p % GW) & (T::BW - 1)) == 0) { rs[c] = o[p].r; gs[c] = o[p].g; bs[c] = o[p].b; }
-            else { rs[c] += o[p].r; gs[c] += o[p].g; bs[c] += o[p].b; }
-            wput<WIDE>(out.y[dy], i, ofloor<TAB == 2>(tfma(K.cyr, o[p].r, tfma(K.cyg, o[p].g, tfma(K.cyb, o[p].b, K.yob))), K.max_o));
-        }
-#pragma unroll
-        for (int c = 0; c < NCG; c++) {
-            const int j = g * NCG + c;
-            wput<WIDE>(out.cb, j, ofloor<TAB == 2>(tfma(K.cbr, rs[c], tfma(K.cbg, gs[c], tfma(K.cbb, bs[c], K.cob))), K.max_o));
-            wput<WIDE>(out.cr, j, ofloor<TAB == 2>(tfma(K.crr, rs[c], tfma(K.crg, gs[c], tfma(K.crb, bs[c], K.cob))), K.max_o));
-        }
-        // emit the unit group by group (see fence_words)
-        fence_words<T::YW * T::BH>(&in.y[0][0]);
-        fence_words<T::CW>(in.cb);
-        fence_words<T::CW>(in.cr);
-        fence_words<T::YW * T::BH>(&out.y[0][0]);
-        fence_words<T::CW>(out.cb);
-        fence_words<T::CW>(out.cr);
-    }
-}
-
-// Bounds-only pass: the cells a tile touches, without taps, blend or outputs (about a quarter of a full
-// pass).  Run on the first tile of a chunk, where the wave's window comes from somewhere else on the
-// frame and an optimistic full pass would almost surely be thrown away.  Does not consume `in`.
-template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
-__device__ __forceinline__ void yuv_tile_bounds(const LutConsts &L, const YuvConsts &K, YuvTile<WIDE, CSX, CSY> &in, Bnd &bn)
-{
-    // consumes `in` like the full body (ordering fences), so the caller re-loads the tile afterwards
-    using T = YuvTile<WIDE, CSX, CSY>;
-#pragma unroll
-    for (int j = 0; j < T::NC; j++) {
-        float cbv = wsample<WIDE>(in.cb, j), crv = wsample<WIDE>(in.cr, j);
-        if constexpr (PRE) {
-            cbv = cfloor(tfma(K.pc, cbv, K.pcb), K.pre_max);
-            crv = cfloor(tfma(K.pc, crv, K.pcb), K.pre_max);
-        }
-        const float cbd = cbv - K.coff, crd = crv - K.coff;
-        const float rv = K.krv * crd, gv = tfma(K.kgu, cbd, K.kgv * crd), bu = K.kbu * cbd;
-#pragma unroll
-        for (int dy = 0; dy < T::BH; dy++) {
-#pragma unroll
-            for (int dx = 0; dx < T::BW; dx++) {
-                float yv = wsample<WIDE>(in.y[dy], j * T::BW + dx);
-                if constexpr (PRE) yv = cfloor(tfma(K.py, yv, K.pyb), K.pre_max);
-                const float yy = tfma(K.ky, yv, K.yb);
-                if constexpr (TAB) {
-                    const unsigned mi = (unsigned)K.max_l;
-                    bnd_update(bn, crd_table(min((unsigned)(yy + rv), mi)).p, crd_table(min((unsigned)(yy + gv), mi)).p,
-                               crd_table(min((unsigned)(yy + bu), mi)).p);
-                } else {
-                    bnd_update(bn, crd_compute<INTERP>(L, cfloor(yy + rv, K.max_l), L.sc[0]).p,
-                               crd_compute<INTERP>(L, cfloor(yy + gv, K.max_l), L.sc[1]).p,
-                               crd_compute<INTERP>(L, cfloor(yy + bu, K.max_l), L.sc[2]).p);
-                }
-            }
-        }
-        fence_words<T::YW * T::BH>(&in.y[0][0]);
-        fence_words<T::CW>(in.cb);
-        fence_words<T::CW>(in.cr);
-        asm volatile("" : "+v"(bn.rmin), "+v"(bn.rmax), "+v"(bn.gmin), "+v"(bn.gmax), "+v"(bn.bmin), "+v"(bn.bmax));
-    }
-}
-
-// 4 waves per SIMD: the kernel needs 127 VGPRs once the input tile is consumed in place (keeping
-// a pristine copy for the rare miss pass cost 41 registers).  5 waves (96 VGPRs) spills into
-// the hot loop and is slower (232 vs 284 Gpx/s on UHD yuv420p10le tetrahedral).
+// ================================================================= work distribution
+// 4 waves per SIMD: the kernel needs 109 VGPRs once the input tile is consumed in place (keeping
+// a pristine copy for the rare miss pass cost 41 registers); 5 waves (96 VGPRs) spills into the hot loop.
 #ifndef LUTR_TILE_WAVES_PER_EU
 #define LUTR_TILE_WAVES_PER_EU 4
 #endif
@@ -729,135 +577,6 @@ __device__ __forceinline__ bool claim_chunk(const TileGeom &TG, int lane, int &f
     return chunk_at(TG, c, fr, sx, ry, rem);
 }
 
-template <int WIDE, int CSX, int CSY, int INTERP, bool PRE, int TAB>
-__global__ __launch_bounds__(64 * LUTR_WPB, LUTR_TILE_WAVES_PER_EU)
-void k_yuv_tile(LutConsts L_, YuvConsts K_, TilePlanes P, FrameGeom G, TileGeom TG)
-{
-    LutConsts L = L_;
-    YuvConsts K = K_;
-    // used 3 times per pixel each by full-rate ops (see in_vgpr); the trilinear bodies have no registers to spare
-    if constexpr (LUTR_PIN_CONSTS && INTERP != LUTR_INTERP_TRILINEAR) {
-        L.maxf = in_vgpr(L_.maxf);
-        K.cyr = in_vgpr(K_.cyr); K.cyg = in_vgpr(K_.cyg); K.cyb = in_vgpr(K_.cyb);
-#if LUTR_PIN_MORE
-        K.ky = in_vgpr(K_.ky); K.yb = in_vgpr(K_.yb); K.yob = in_vgpr(K_.yob);
-#endif
-#if LUTR_PIN_MORE > 1
-        K.krv = in_vgpr(K_.krv); K.kbu = in_vgpr(K_.kbu); K.kgu = in_vgpr(K_.kgu); K.kgv = in_vgpr(K_.kgv);
-#endif
-    }
-    if constexpr (TAB) coord_table_fill<INTERP>(L, TG.tab_bytes / 8);     // the kernel's only barrier
-    using T = YuvTile<WIDE, CSX, CSY>;
-    const int lane = threadIdx.x & 63;
-    const int wib = uni(threadIdx.x >> 6);
-    const int wave = blockIdx.x * LUTR_WPB + wib;
-    const int slice_off = TG.tab_bytes + wib * TG.win_nodes * lds_node<INTERP>();
-    int fr, sx, ry, rem;                                      // the tile being fetched next
-    int round = 0;
-    if (!claim_chunk(TG, lane, fr, sx, ry, rem, round)) return;   // wave-uniform; the first chunks go by wave id
-    const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
-    const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
-    const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
-
-    const int lds_bytes = TG.tab_bytes + LUTR_WPB * TG.win_nodes * lds_node<INTERP>();
-    Win W, WG;
-    win_empty(W, slice_off);
-    win_global(WG, L);
-    bool lds_mode = true;                                     // optimistic; the first tile misses and stages
-    constexpr int CWB = T::CW * 4, YWB = T::YW * 4;
-
-    // Input words of a tile.  Idle lanes of edge tiles re-read a valid unit of the same tile.
-    auto load_tile = [&](T &dst, int f, int tsx, int try_) {
-        const int lxc = min(lx, TG.uw - 1 - tsx * lw), lyc = min(ly, TG.urows - 1 - (try_ << lh_log2));
-        const long long urow0 = cr0 + (try_ << lh_log2);                  // wave-uniform
-        const uint8_t *sy = P.s[0] + f * P.sfs[0] + urow0 * T::BH * (long long)P.ss[0] + (long long)tsx * lw * YWB;
-        const uint8_t *scb = P.s[1] + f * P.sfs[1] + urow0 * (long long)P.ss[1] + (long long)tsx * lw * CWB;
-        const uint8_t *scr = P.s[2] + f * P.sfs[2] + urow0 * (long long)P.ss[2] + (long long)tsx * lw * CWB;
-#pragma unroll
-        for (int dy = 0; dy < T::BH; dy++)
-            ldw<T::YW>(dst.y[dy], sy + (unsigned)((lyc * T::BH + dy) * (int)P.ss[0] + lxc * YWB));
-        ldw<T::CW>(dst.cb, scb + (unsigned)(lyc * (int)P.ss[1] + lxc * CWB));
-        ldw<T::CW>(dst.cr, scr + (unsigned)(lyc * (int)P.ss[2] + lxc * CWB));
-    };
-
-    WaveStats ws;
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-    T nxt;
-    load_tile(nxt, fr, sx, ry);
-    bool nxt_fresh = true;                                    // the tile in `nxt` starts a chunk
-    for (bool more = true; more;) {
-        T in = nxt;
-        const bool fresh = nxt_fresh;
-        nxt_fresh = false;
-        const int cfr = fr, csx = sx, cry = ry;
-        // Next tile: the one below in this chunk, else the first tile of a newly claimed chunk.  Its loads
-        // are issued NOW, before this tile's stores: vmcnt retires in order, so loads issued after the
-        // stores would wait for HBM to acknowledge them.  When the queue is drained the current tile is
-        // simply fetched again, so every path has the same number of memory operations in flight and
-        // hipcc can wait with a counted vmcnt instead of vmcnt(0).
-        if (--rem > 0) ry++;
-        else { more = claim_chunk(TG, lane, fr, sx, ry, rem, round); nxt_fresh = true; }
-        load_tile(nxt, fr, sx, ry);
-
-        T out;
-        Bnd bn;
-        if (fresh) {        // new place on the frame: size the window from a cheap bounds pass first
-            bnd_reset(bn);
-            yuv_tile_bounds<WIDE, CSX, CSY, INTERP, PRE, TAB>(L, K, in, bn);
-            if (!lds_mode || !win_holds(W, bn)) {
-                lds_mode = win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane);
-                if (lds_mode) ws.n[3]++;
-            }
-            load_tile(in, cfr, csx, cry);              // the bounds pass consumed the tile; L2 still has it
-            __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0) here keeps the waits of the main path counted
-        }
-        for (;;) {
-            bnd_reset(bn);
-            if (lds_mode) {
-                yuv_tile_body<true, WIDE, CSX, CSY, INTERP, PRE, TAB>(L, K, W, in, out, bn);
-                if (win_holds(W, bn)) break;
-                // miss: re-stage around this tile's colours and redo it, or give the tile to the gather body
-                ws.n[1]++;
-                if (!win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) lds_mode = false;
-                else ws.n[3]++;
-                load_tile(in, cfr, csx, cry);          // the failed pass consumed the tile; L2 still has it
-                __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0) HERE, or the loop header waits on every pass
-            } else {
-                yuv_tile_body<false, WIDE, CSX, CSY, INTERP, PRE, TAB>(L, K, WG, in, out, bn);
-                ws.n[2]++;
-                // colours narrow enough again?  then the next tile starts from a staged window
-                if (win_restage<lds_node<INTERP>()>(W, L, bn, TG.win_nodes, slice_off, lds_bytes, lane)) { lds_mode = true; ws.n[3]++; }
-                break;
-            }
-        }
-        {
-            // Idle lanes of edge tiles processed a duplicate of a valid unit of this tile (load_tile clamps),
-            // so they store the same bytes to the same place as its owner: no branch, fixed store count.
-            const int lxc = min(lx, TG.uw - 1 - csx * lw), lyc = min(ly, TG.urows - 1 - (cry << lh_log2));
-            const long long urow0 = cr0 + (cry << lh_log2);
-            uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * (long long)P.ds[0] + (long long)csx * lw * YWB;
-            uint8_t *dcb = P.d[1] + cfr * P.dfs[1] + urow0 * (long long)P.ds[1] + (long long)csx * lw * CWB;
-            uint8_t *dcr = P.d[2] + cfr * P.dfs[2] + urow0 * (long long)P.ds[2] + (long long)csx * lw * CWB;
-#pragma unroll
-            for (int dy = 0; dy < T::BH; dy++)
-                stw<T::YW>(dy_ + (unsigned)((lyc * T::BH + dy) * (int)P.ds[0] + lxc * YWB), out.y[dy]);
-            stw<T::CW>(dcb + (unsigned)(lyc * (int)P.ds[1] + lxc * CWB), out.cb);
-            stw<T::CW>(dcr + (unsigned)(lyc * (int)P.ds[2] + lxc * CWB), out.cr);
-        }
-        ws.n[0]++;
-    }
-    ws.flush(TG.stats, lane);
-    if (TG.stats && lane == 0) {                           // load balance: longest and summed wave lifetimes (100 MHz ticks)
-        const unsigned life = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
-        atomicMax(&TG.stats[10], life);
-        atomicAdd(&TG.stats[11], life >> 6);
-    }
-    if (TG.stats && lane == 0 && (wave & 255) == 0) {      // a few waves report their clock: cycles / 100 MHz ticks
-        atomicAdd(&TG.stats[4], (unsigned)((__builtin_amdgcn_s_memtime() - clk0) >> 8));
-        atomicAdd(&TG.stats[5], (unsigned)((__builtin_amdgcn_s_memrealtime() - rt0) >> 8));
-    }
-}
-
 // ================================================================= planar RGB tile kernel
 template <int WIDE>
 struct RgbTile {
@@ -876,7 +595,7 @@ template <bool LDS, int WIDE, int INTERP, int TAB>
 __device__ __forceinline__ void rgb_tile_body(const LutConsts &L, const Win &W, RgbTile<WIDE> &in,
                                               RgbTile<WIDE> &out, Bnd &bn)
 {
-    // `in` is consumed (see yuv_tile_body).  Groups of 4 pixels, staged: coordinates for all four,
+    // `in` is consumed: the ordering fences run its words through volatile asm, so the caller re-loads the tile before a second pass.  Groups of 4 pixels, staged: coordinates for all four,
     // then taps + blend, then packing, so neighbouring instructions are independent.
 #pragma unroll
     for (int k = 0; k < 4; k++) { out.g[k] = 0; out.b[k] = 0; out.r[k] = 0; }
@@ -938,7 +657,8 @@ __global__ __launch_bounds__(64 * LUTR_WPB, LUTR_TILE_WAVES_PER_EU)
 void k_rgb_tile(LutConsts L_, TilePlanes P, FrameGeom G, TileGeom TG)
 {
     LutConsts L = L_;
-    if constexpr (LUTR_PIN_CONSTS && INTERP != LUTR_INTERP_TRILINEAR) L.maxf = in_vgpr(L_.maxf);
+    // used 3 times per pixel by full-rate ops: worth a VGPR (an SGPR source drops them to the slow issue class)
+    if constexpr (INTERP != LUTR_INTERP_TRILINEAR) L.maxf = in_vgpr(L_.maxf);
     if constexpr (TAB) coord_table_fill<INTERP>(L, TG.tab_bytes / 8);
     using T = RgbTile<WIDE>;
     const int lane = threadIdx.x & 63;
@@ -974,7 +694,7 @@ void k_rgb_tile(LutConsts L_, TilePlanes P, FrameGeom G, TileGeom TG)
         const bool fresh = nxt_fresh;
         nxt_fresh = false;
         const int cfr = fr, csx = sx, cry = ry;
-        if (--rem > 0) ry++;                    // next tile of the chunk, or a new chunk (see k_yuv_tile)
+        if (--rem > 0) ry++;                    // next tile of the chunk, or a new chunk 
         else { more = claim_chunk(TG, lane, fr, sx, ry, rem, round); nxt_fresh = true; }
         load_tile(nxt, fr, sx, ry);
 
@@ -1142,61 +862,6 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     RGB_CASE(0, 0) RGB_CASE(0, 1) RGB_CASE(0, 2)
     RGB_CASE(1, 0) RGB_CASE(1, 1) RGB_CASE(1, 2)
 #undef RGB_CASE
-    return nullptr;
-}
-
-// Can min(v, max_o) of the RGB -> YUV side ever bind?  Inputs are integer codes in [0, max_l] (sums of
-// chroma_n of them for Cb/Cr); every chain is monotone in each input (rounding is monotone), so its
-// maximum is the same float expression evaluated at the corner that maximises each term.
-static bool out_clip_dead(const YuvConsts &K, int chroma_n)
-{
-    const float m = K.max_l, mn = K.max_l * (float)chroma_n;
-    auto hi = [](float c, float v) { return c > 0.0f ? v : 0.0f; };
-    const float y = fmaf(K.cyr, hi(K.cyr, m), fmaf(K.cyg, hi(K.cyg, m), fmaf(K.cyb, hi(K.cyb, m), K.yob)));
-    const float cb = fmaf(K.cbr, hi(K.cbr, mn), fmaf(K.cbg, hi(K.cbg, mn), fmaf(K.cbb, hi(K.cbb, mn), K.cob)));
-    const float cr = fmaf(K.crr, hi(K.crr, mn), fmaf(K.crg, hi(K.crg, mn), fmaf(K.crb, hi(K.crb, mn), K.cob)));
-    const float lim = K.max_o + 1.0f;
-    return y < lim && cb < lim && cr < lim;
-}
-
-const char *launch_yuv_tile(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,
-                            const FrameGeom &G, int win, int csx, int csy, int mode, unsigned *stats, unsigned *queue)
-{
-    const int pxt = win ? 8 : 16;
-    TileGeom tg;
-    read_env_tuning();
-    plan_tiles(&tg, G.w / pxt, G.rows >> csy, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
-    const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
-    // the queue starts behind the chunks the waves take by their id (claim_chunk)
-    if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_WPB * LUTR_STATIC_ROUNDS), 1, st) != hipSuccess) return nullptr;
-    const bool tab = plan_table(&tg, L, lds_node_rt(mode)) != 0;
-    const TilePlanes TP = tile_planes(P);
-    const size_t lds = (size_t)tg.tab_bytes + (size_t)LUTR_WPB * tg.win_nodes * lds_node_rt(mode);
-    const bool pre = K.pre != 0.0f;
-    // ",unit" kernels drop both output clips: lattice in [0,1] (quantisation) and YUV maxima below max_o + 1
-    const bool unit = L.unit && out_clip_dead(K, 1 << (csx + csy));
-    if (getenv("LUTR_DEBUG")) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_yuv_tile<1, 1, 1, 2, false, 1>, 64 * LUTR_WPB, lds);
-        fprintf(stderr, "[lutr] tiles %d nsx %d nry %d chunk %d nrc %d chunks %d blocks %u lds/block %zu occupancy(blocks/CU) %d cus %d\n",
-                tg.tiles, tg.nsx, tg.nry, tg.ch, tg.nrc, tg.nchunks, grid.x, lds, nb, device_cus());
-    }
-#define YUV_CASE(W, X, Y, I) \
-    if (win == W && csx == X && csy == Y && mode == I) { \
-        if (pre && tab) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, true, 1>), L, K, TP, G, tg); \
-        else if (pre) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, true, 0>), L, K, TP, G, tg); \
-        else if (tab && unit) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 2>), L, K, TP, G, tg); \
-        else if (tab) LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 1>), L, K, TP, G, tg); \
-        else LUTR_LAUNCH_TILE((k_yuv_tile<W, X, Y, I, false, 0>), L, K, TP, G, tg); \
-        return pre ? (tab ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre,tab>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",pre>") \
-                   : (tab ? (unit ? "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab,unit>" : "k_yuv_tile<" #W "," #X "," #Y "," #I ",tab>") \
-                          : "k_yuv_tile<" #W "," #X "," #Y "," #I ">"); \
-    }
-#define YUV_FMT(W, X, Y) YUV_CASE(W, X, Y, 0) YUV_CASE(W, X, Y, 1) YUV_CASE(W, X, Y, 2)
-    YUV_FMT(0, 1, 1) YUV_FMT(0, 1, 0) YUV_FMT(0, 0, 0)
-    YUV_FMT(1, 1, 1) YUV_FMT(1, 1, 0) YUV_FMT(1, 0, 0)
-#undef YUV_FMT
-#undef YUV_CASE
     return nullptr;
 }
 

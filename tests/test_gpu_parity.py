@@ -704,7 +704,7 @@ def test_randomised_differential_sweep(engine, orc, tmp_path):
             g = g.view(np.uint16) if esz == 2 else g
             for fr in range(nf):
                 _assert_equal([g[fr]], [want[fr][i]], f"{what} plane {i} frame {fr} ({engine.last_kernel})")
-    assert {"k_yuv_tile", "k_rgb_tile", "k_yuv_generic", "k_rgb_generic"} <= kernels, kernels
+    assert {"k_yuv_tile2", "k_rgb_tile", "k_yuv_generic", "k_rgb_generic"} <= kernels, kernels
 
 
 def test_contexts_on_concurrent_threads(orc, cube_dir):

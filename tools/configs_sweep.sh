@@ -1,15 +1,23 @@
 #!/bin/bash
 # tools/configs_sweep.sh -- one bench line per BASELINE.json config / format family (1 GPU), as a table.
-run() { timeout -k 10 200 python bench.py --no-cpu-baseline --steps 40 --warmup 10 "$@" 2>/dev/null | python -c "
+# Column "other" = the other precision (strict when the line ran fast) timed on the same batch.
+run() { timeout -k 10 200 python bench.py --no-cpu-baseline --no-extra --steps 40 --warmup 10 "$@" 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']; w=c.get('lds_window') or {}
-print('| %-62s | %9.0f | %6.0f | %5.1f%% | %s | %s |' % (c['workload'].split(', row-block')[0][:62], d['value'], r['achieved'], 100*r['frac'], c['kernel'], '%d/%d/%d' % (w.get('tiles',0), w.get('misses',0), w.get('global_tiles',0))))"; }
-echo "| workload | Mpx/s | GB/s | of 8 TB/s | kernel | tiles/miss/gather |"
-echo "|---|---|---|---|---|---|"
+d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']; w=c.get('lds_window') or {}; o=d.get('other_precision') or {}
+print('| %-70s | %-6s | %9.0f | %6.0f | %5.1f%% | %9s | %s | %s |' % (c['workload'].split(', row-block')[0].replace(' resident in HBM','')[:70], c['precision'], d['value'], r['achieved'], 100*r['frac'], ('%.0f' % o['Mpx_s']) if o else '-', c['kernel'], '%d/%d/%d/%d' % (w.get('tiles',0), w.get('level2_tiles',0), w.get('misses',0), w.get('global_tiles',0))))"; }
+echo "| workload | precision | Mpx/s | GB/s | of 8 TB/s | other Mpx/s | kernel | tiles/level-2/restaged/gather |"
+echo "|---|---|---|---|---|---|---|---|"
 run --size uhd --fmt yuv420p10le --interp tetrahedral
 run --size uhd --fmt yuv420p10le --interp trilinear
-run --size uhd --fmt yuv420p10le --interp tetrahedral --dist uniform
+run --size uhd --fmt yuv420p10le --interp tetrahedral --dist noise8 --frames 64
+run --size uhd --fmt yuv420p10le --interp tetrahedral --dist noise16 --frames 64
+run --size uhd --fmt yuv420p10le --interp tetrahedral --dist uniform --frames 64
 run --size uhd --fmt yuv420p10le --interp tetrahedral --lut 65
+run --size uhd --fmt yuv420p10le --interp tetrahedral --lut 17
+run --size uhd --fmt yuv420p10le --interp tetrahedral --lut 17 --dist uniform --frames 64
+run --size uhd --fmt yuv420p10le --out-fmt yuv420p --interp tetrahedral
+run --size uhd --fmt yuv420p10le --range-src pc --interp tetrahedral
+run --size uhd --fmt yuv420p10le --range-src pc --out-fmt yuv420p --interp tetrahedral
 run --size 1080p --fmt yuv420p --interp trilinear --frames 64
 run --size 1080p --fmt yuv420p --interp tetrahedral --frames 64
 run --size 8k --fmt yuv420p10le --interp tetrahedral --frames 8
