@@ -133,10 +133,17 @@ template <int INTERP, int V> struct Node {
 struct Win {
     float fr, fg, fb, fc;        // LDS byte address of the c000 tap: (int) fma(pr, fr, fma(pg, fg, fma(pb, fb, fc)))
     int   o_r, o_g;              // byte steps of +1 along r and g (blue is one node)
-    // raw-code box this window is good for, each bound replicated in both 16-bit halves (8-bit planes: code << 8,
-    // upper bounds | 0xff -- see extremes())
-    uint32_t ylo, yhi, cblo, cbhi, crlo, crhi;
 };
+// The raw-code box a window is good for lives in the wave's LDS scratch, not in registers: {ylo, yhi, cblo, cbhi} at +32,
+// {crlo, crhi} at +48, each bound replicated in both 16-bit halves (8-bit planes: code << 8, upper bounds | 0xff -- see
+// extremes()).  Registers are what this kernel runs out of, and a value spilled to scratch is worse than it looks: a
+// scratch_load in the per-tile path makes the wave wait with vmcnt(0), i.e. for the next tile's prefetch it has just issued.
+struct Box { uint32_t ylo, yhi, cblo, cbhi, crlo, crhi; };
+DEV void box_store(int scratch_off, const Box &b)
+{
+    *(uint4 *)(smem + scratch_off + 32) = make_uint4(b.ylo, b.yhi, b.cblo, b.cbhi);
+    *(uint2 *)(smem + scratch_off + 48) = make_uint2(b.crlo, b.crhi);
+}
 
 struct Ext { uint32_t ymin, ymax, cbmin, cbmax, crmin, crmax; };   // packed per-lane extremes of a unit
 
@@ -264,11 +271,15 @@ DEV Ext extremes(const TileIn<WIN, WOUT, CSX, CSY> &in)
     return e;
 }
 
-DEV bool box_holds(const Win &W, const Ext &e)
+DEV uint32_t pk_subsat(uint32_t a, uint32_t b) { uint32_t o; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(o) : "v"(a), "v"(b)); return o; }
+
+DEV bool box_holds(int scratch_off, const Ext &e)
 {
+    const uint4 p = *(const uint4 *)(smem + scratch_off + 32);      // ylo, yhi, cblo, cbhi
+    const uint2 q = *(const uint2 *)(smem + scratch_off + 48);      // crlo, crhi
     // every half >= lo and <= hi  <=>  all six saturating differences are zero
-    const uint32_t a = pk_subsat_sv(W.ylo, e.ymin) | pk_subsat_vs(e.ymax, W.yhi) | pk_subsat_sv(W.cblo, e.cbmin);
-    const uint32_t b = pk_subsat_vs(e.cbmax, W.cbhi) | pk_subsat_sv(W.crlo, e.crmin) | pk_subsat_vs(e.crmax, W.crhi);
+    const uint32_t a = pk_subsat(p.x, e.ymin) | pk_subsat(e.ymax, p.y) | pk_subsat(p.z, e.cbmin);
+    const uint32_t b = pk_subsat(e.cbmax, p.w) | pk_subsat(q.x, e.crmin) | pk_subsat(e.crmax, q.y);
     return __all((a | b) == 0u);
 }
 
@@ -406,7 +417,7 @@ DEV Bnd tile_bounds(const LutConsts &L, const YuvConsts &K, const Geom &TG, Tile
     return bn;
 }
 
-// the window's cell ranges live in the wave's 32-byte LDS scratch (they are only read on the second-level path)
+// the window's cell ranges live in the wave's 64-byte LDS scratch (they are only read on the second-level path)
 DEV bool cells_hold(int scratch_off, const Bnd &b)
 {
     const float4 lo = *(const float4 *)(smem + scratch_off);        // r_lo, g_lo, b_lo, r_hi
@@ -563,12 +574,16 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
     W.o_r = kLN * (sr - nb - 1); W.o_g = kLN * nb;
     W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)kLN;
     W.fc = (float)(lds_base() + slice_off - kLN * (r0 * sr + g0 * nb + b0));
-    if (by1 >= by0) {
-        W.ylo = pack_lo<WIN>(by0); W.yhi = pack_hi<WIN>(by1);
-        W.cblo = pack_lo<WIN>(bcb0); W.cbhi = pack_hi<WIN>(bcb1);
-        W.crlo = pack_lo<WIN>(bcr0); W.crhi = pack_hi<WIN>(bcr1);
-    } else {
-        W.ylo = W.cblo = W.crlo = 0xffffffffu; W.yhi = W.cbhi = W.crhi = 0u;
+    if (lane == 0) {
+        Box bx;
+        if (by1 >= by0) {
+            bx.ylo = pack_lo<WIN>(by0); bx.yhi = pack_hi<WIN>(by1);
+            bx.cblo = pack_lo<WIN>(bcb0); bx.cbhi = pack_hi<WIN>(bcb1);
+            bx.crlo = pack_lo<WIN>(bcr0); bx.crhi = pack_hi<WIN>(bcr1);
+        } else {
+            bx.ylo = bx.cblo = bx.crlo = 0xffffffffu; bx.yhi = bx.cbhi = bx.crhi = 0u;      // empty: lo > hi
+        }
+        box_store(scratch_off, bx);
     }
     return true;
 }
@@ -901,7 +916,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     }
     if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier ...
     if (TG.whole) {                                                             // ... but for this one, in whole-lattice mode
-        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 32;
+        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
         const int nodes = L.n1 * L.n1 * L.n1;
         for (int i = threadIdx.x; i < nodes; i += 64 * LUTR_T2_WPB) {
             if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[i];
@@ -916,8 +931,8 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int tab_bytes = TG.tab_entries * 8;
-    const int scratch_off = tab_bytes + wib * 32;             // the window's cell ranges (second-level test)
-    const int slice_off = tab_bytes + LUTR_T2_WPB * 32 + wib * TG.win_nodes * N::lds;
+    const int scratch_off = tab_bytes + wib * 64;             // the window's cell ranges (second-level test)
+    const int slice_off = tab_bytes + LUTR_T2_WPB * 64 + wib * TG.win_nodes * N::lds;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     bool first = true;
     if (!claim_chunk(TG, lane, fr, sx, ry, rem, first)) return;
@@ -927,13 +942,16 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
 
     Win W;
     W.fr = W.fg = W.fb = W.fc = 0.0f; W.o_r = W.o_g = 0;
-    // empty box: lo > hi in every plane, so the first tile always restages
-    W.ylo = W.cblo = W.crlo = 0xffffffffu; W.yhi = W.cbhi = W.crhi = 0u;
+    if (lane == 0) {     // empty box: lo > hi in every plane, so the first tile always restages
+        Box bx;
+        bx.ylo = bx.cblo = bx.crlo = 0xffffffffu; bx.yhi = bx.cbhi = bx.crhi = 0u;
+        box_store(scratch_off, bx);
+    }
     if (TG.whole) {
         // lattice layout of the global copy ((N+1)^3 nodes, blue fastest, index N replicates N-1): prev + 1 is always staged
         W.o_r = N::lds * L.n1 * L.n1; W.o_g = N::lds * L.n1;
         W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)N::lds;
-        W.fc = (float)(lds_base() + tab_bytes + LUTR_T2_WPB * 32);
+        W.fc = (float)(lds_base() + tab_bytes + LUTR_T2_WPB * 64);
     }
     constexpr int YIB = T::YWI * 4, YOB = T::YWO * 4, CIB = T::CWI * 4, COB = T::CWO * 4;
 
@@ -952,7 +970,12 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     };
 
     bool have_win = false;
-    unsigned st_tiles = 0, st_miss = 0, st_gather = 0, st_staged = 0, st_level2 = 0;
+    // event counters (lutr_ctx_tile_stats): kept in the wave's LDS scratch, not in registers (see Box)
+    const bool counting = TG.stats != nullptr;
+    unsigned *cnt = (unsigned *)(smem + scratch_off + 24);      // [0] second-level tests, [1] restage attempts; +56: [8] gather, [9] staged
+    if (lane == 0) { cnt[0] = cnt[1] = 0; cnt[8] = cnt[9] = 0; }
+    unsigned st_tiles = 0;
+#define T2_COUNT(i) do { if (counting && lane == 0) cnt[i] += 1u; } while (0)
 #ifdef LUTR_T2_DEBUG_STATS
     unsigned tk_head = 0, tk_l2 = 0, tk_rest = 0, tk_body = 0, tk_gath = 0, tk_store = 0;
     unsigned long long tk = __builtin_amdgcn_s_memrealtime();
@@ -988,15 +1011,16 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
 #define LUTR_T2_EXP 0             // timing experiments only (wrong pixels): 1 = trust the first window forever, 2 = + no stores, 3 = no body
 #endif
         const Ext e = extremes<WIN, WOUT, CSX, CSY>(in);
-        bool use_lds = box_holds(W, e);                       // first level: raw extremes against the window's raw box
+        bool use_lds = box_holds(scratch_off, e);             // first level: raw extremes against the window's raw box
         if (LUTR_T2_EXP >= 1 && have_win) use_lds = true;
         TK(tk_head)
+        st_tiles++;
         if (TG.whole) {
             // every cell is in LDS; only raw codes above 2^din - 1 (which the padded table does not cover) need the clamping body
             const uint32_t top = pack_hi<WIN>(TG.max_raw);
             use_lds = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
         } else if (!use_lds) {
-            st_level2++;
+            T2_COUNT(0);
 
             const Bnd bn = tile_bounds<WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, TG, in);
             // second level: exact cells against the window's cell ranges (raw codes must be legal for the clamp-free body)
@@ -1005,9 +1029,9 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             use_lds = have_win && legal && cells_hold(scratch_off, bn);
             TK(tk_l2)
             if (!use_lds) {
-                st_miss++;
+                T2_COUNT(1);
                 use_lds = restage<WIN, INTERP, PRE, V>(W, L, K, TG, e, bn, slice_off, scratch_off, lane);
-                if (use_lds) { st_staged++; have_win = true; }
+                if (use_lds) { T2_COUNT(9); have_win = true; }
                 TK(tk_rest)
             }
         }
@@ -1024,7 +1048,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out); TK(tk_body)
             if (LUTR_T2_EXP == 4) tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out);
         }
-        else { tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out); st_gather++; TK(tk_gath) }
+        else { tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out); T2_COUNT(8); TK(tk_gath) }
         {
             // Idle lanes of edge tiles processed a duplicate of a valid unit of this tile (load_tile clamps), so they
             // store the same bytes to the same place as its owner: no branch, fixed store count.
@@ -1041,7 +1065,6 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             stw<T::CWO>(dcr + (unsigned)(lyc * (int)P.ds[2] + lxc * COB), out.cr);
             }
         }
-        st_tiles++;
         TK(tk_store)
     }
 #ifdef LUTR_T2_DEBUG_STATS
@@ -1051,8 +1074,8 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     }
 #endif
     if (TG.stats && lane == 0) {
-        atomicAdd(&TG.stats[0], st_tiles); atomicAdd(&TG.stats[1], st_miss);
-        atomicAdd(&TG.stats[2], st_gather); atomicAdd(&TG.stats[3], st_staged); atomicAdd(&TG.stats[6], st_level2);
+        atomicAdd(&TG.stats[0], st_tiles); atomicAdd(&TG.stats[1], cnt[1]);
+        atomicAdd(&TG.stats[2], cnt[8]); atomicAdd(&TG.stats[3], cnt[9]); atomicAdd(&TG.stats[6], cnt[0]);
     }
 }
 
@@ -1166,19 +1189,19 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     tg.max_raw = (1 << din) - 1;
     const int node = vv == V_FAST ? 8 : (mode == LUTR_INTERP_TRILINEAR ? 16 : 12);
     const int blocks_per_cu = waves_per_cu / LUTR_T2_WPB > 0 ? waves_per_cu / LUTR_T2_WPB : 1;
-    int cap = (163840 / blocks_per_cu - tg.tab_entries * 8 - 32 * LUTR_T2_WPB) / (node * LUTR_T2_WPB);
+    int cap = (163840 / blocks_per_cu - tg.tab_entries * 8 - 64 * LUTR_T2_WPB) / (node * LUTR_T2_WPB);
     if (const char *e = getenv("LUTR_WIN_NODES")) { const int c = atoi(e); if (c >= 64 && c < cap) cap = c; }
     // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
     tg.whole = (blocks_per_cu == 1 && !getenv("LUTR_NO_WHOLE") &&
-                tg.tab_entries * 8 + 32 * LUTR_T2_WPB + whole_bytes <= 163840) ? 1 : 0;
+                tg.tab_entries * 8 + 64 * LUTR_T2_WPB + whole_bytes <= 163840) ? 1 : 0;
     if (!tg.whole && cap < 128) return nullptr;
     tg.win_nodes = tg.whole ? 0 : cap;
     tg.queue = queue; tg.stats = stats;
     const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
     const dim3 grid((waves + LUTR_T2_WPB - 1) / LUTR_T2_WPB), block(64 * LUTR_T2_WPB);
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_T2_WPB), 1, st) != hipSuccess) return nullptr;
-    const size_t lds = (size_t)tg.tab_entries * 8 + 32 * LUTR_T2_WPB +
+    const size_t lds = (size_t)tg.tab_entries * 8 + 64 * LUTR_T2_WPB +
                        (tg.whole ? (size_t)whole_bytes : (size_t)LUTR_T2_WPB * tg.win_nodes * node);
     Planes2 TP;
     for (int i = 0; i < 3; i++) {
