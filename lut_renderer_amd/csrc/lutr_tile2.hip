@@ -444,6 +444,51 @@ template <int WIN> DEV int hi_of(uint32_t mx) { const int a = (int)(mx & 0xffffu
 template <int WIN> DEV uint32_t pack_lo(int v) { const uint32_t h = WIN ? (uint32_t)v : (uint32_t)v << 8; return h | (h << 16); }
 template <int WIN> DEV uint32_t pack_hi(int v) { const uint32_t h = WIN ? (uint32_t)v : ((uint32_t)v << 8) | 0xffu; return h | (h << 16); }
 
+// The window holds this tile (second-level test) but its raw box does not -- typically a window that was staged around the
+// exact cells of an edge tile and has no box at all.  Try to give it one without staging anything: the largest of a few raw
+// boxes around this tile's raw extremes whose conservative cell map lies inside the window's cell ranges.  Called with
+// back-off (1st, 4th, 16th consecutive second-level pass), so a wave leaves the expensive mode once it is past the edge.
+template <int WIN, int INTERP, int PRE, int V>
+DEV void rebox(const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext &e_, int scratch_off, int lane)
+{
+    Ext e = e_;
+    asm volatile("" : "+v"(e.ymin), "+v"(e.ymax), "+v"(e.cbmin), "+v"(e.cbmax), "+v"(e.crmin), "+v"(e.crmax));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        e.ymin = pk_min(e.ymin, shx(e.ymin, m)); e.ymax = pk_max(e.ymax, shx(e.ymax, m));
+        e.cbmin = pk_min(e.cbmin, shx(e.cbmin, m)); e.cbmax = pk_max(e.cbmax, shx(e.cbmax, m));
+        e.crmin = pk_min(e.crmin, shx(e.crmin, m)); e.crmax = pk_max(e.crmax, shx(e.crmax, m));
+    }
+    const int y0 = uni(lo_of<WIN>(e.ymin)), y1 = uni(hi_of<WIN>(e.ymax));
+    const int cb0 = uni(lo_of<WIN>(e.cbmin)), cb1 = uni(hi_of<WIN>(e.cbmax));
+    const int cr0 = uni(lo_of<WIN>(e.crmin)), cr1 = uni(hi_of<WIN>(e.crmax));
+    const int mr = TG.max_raw;
+    const float4 lo = *(const float4 *)(smem + scratch_off);        // r_lo, g_lo, b_lo, r_hi
+    const float2 hi = *(const float2 *)(smem + scratch_off + 16);   // g_hi, b_hi
+    const int wr0 = uni((int)lo.x), wg0 = uni((int)lo.y), wb0 = uni((int)lo.z), wr1 = uni((int)lo.w), wg1 = uni((int)hi.x), wb1 = uni((int)hi.y);
+    const float cell_y = L.maxf / (L.lut_max * K.ky * (PRE ? K.py : 1.0f));
+    const int unit = (mr + 1) >> 8;
+#pragma unroll 1
+    for (int t = 0; t < 3; t++) {
+        const int mc = t == 0 ? unit : (t == 1 ? (unit + 3) / 4 : 0);
+        const int my = t == 2 ? 0 : (int)((t == 0 ? 1.5f : 0.5f) * cell_y);
+        const int ty0 = max(y0 - my, 0), ty1 = min(y1 + my, mr);
+        const int tcb0 = max(cb0 - mc, 0), tcb1 = min(cb1 + mc, mr), tcr0 = max(cr0 - mc, 0), tcr1 = min(cr1 + mc, mr);
+        const Cells c = map_box<INTERP, PRE, V>(L, K, TG, (float)ty0, (float)ty1, (float)tcb0, (float)tcb1, (float)tcr0, (float)tcr1);
+        const bool fits = uni((int)(c.r0 >= wr0 && c.r1 <= wr1 && c.g0 >= wg0 && c.g1 <= wg1 && c.b0 >= wb0 && c.b1 <= wb1)) != 0;
+        if (fits) {
+            if (lane == 0) {
+                Box bx;
+                bx.ylo = pack_lo<WIN>(ty0); bx.yhi = pack_hi<WIN>(ty1);
+                bx.cblo = pack_lo<WIN>(tcb0); bx.cbhi = pack_hi<WIN>(tcb1);
+                bx.crlo = pack_lo<WIN>(tcr0); bx.crhi = pack_hi<WIN>(tcr1);
+                box_store(scratch_off, bx);
+            }
+            return;
+        }
+    }
+}
+
 // Neither test vouches for the tile: stage a new window around the tile's EXACT cells (spare cells on the two
 // chroma-like axes as capacity allows, the luma-like axis gets the rest), then look for the largest raw box around the
 // tile's raw extremes whose conservative cell map (map_box) lies inside what was staged: that box is what the cheap
@@ -970,6 +1015,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     };
 
     bool have_win = false;
+    int l2run = 0;                 // consecutive tiles vouched for by the second-level test only
     // event counters (lutr_ctx_tile_stats): kept in the wave's LDS scratch, not in registers (see Box)
     const bool counting = TG.stats != nullptr;
     unsigned *cnt = (unsigned *)(smem + scratch_off + 24);      // [0] second-level tests, [1] restage attempts; +56: [8] gather, [9] staged
@@ -1019,7 +1065,9 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             // every cell is in LDS; only raw codes above 2^din - 1 (which the padded table does not cover) need the clamping body
             const uint32_t top = pack_hi<WIN>(TG.max_raw);
             use_lds = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
-        } else if (!use_lds) {
+        } else if (use_lds) {
+            l2run = 0;
+        } else {
             T2_COUNT(0);
 
             const Bnd bn = tile_bounds<WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, TG, in);
@@ -1028,6 +1076,12 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             const bool legal = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
             use_lds = have_win && legal && cells_hold(scratch_off, bn);
             TK(tk_l2)
+            if (use_lds) {
+                l2run++;
+                if (l2run == 1 || l2run == 4 || l2run == 16) rebox<WIN, INTERP, PRE, V>(L, K, TG, e, scratch_off, lane);
+            } else {
+                l2run = 0;
+            }
             if (!use_lds) {
                 T2_COUNT(1);
                 use_lds = restage<WIN, INTERP, PRE, V>(W, L, K, TG, e, bn, slice_off, scratch_off, lane);
