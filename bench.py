@@ -75,6 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-stats", action="store_true", help="skip the extra LDS-window statistics pass (profiling runs)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other-content lines (extra_Mpx_s)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling pass (N > 1)")
+    ap.add_argument("--no-other", action="store_true", help="skip timing the other precision (profiling runs: one kernel only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="wall budget of the CPU baseline sample (all host cores: ~10 s wall on 256 threads)")
     ap.add_argument("--extra-modes", action="store_true", help="extra_Mpx_s also for trilinear")
@@ -370,7 +371,7 @@ def main():
 
     # the other precision on the same batch (N = 1): the line always carries both numbers
     other = None
-    if world == 1 and pf.family == "yuv" and args.dither == "none":
+    if world == 1 and pf.family == "yuv" and args.dither == "none" and not args.no_other:
         oname = "strict" if args.precision == "fast" else "fast"
         eng.set_precision(oname)
         _, ok = time_steps(eng, job, src, dst, args.interp, max(5, args.steps // 4), 3, 1, r0, r1 - r0)

@@ -24,14 +24,22 @@ for f in sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")))[-1:]:
     summary["kernel_stats"] = [{k: r[k][:120] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")}
                                for r in rows[:3]]
 for f in sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_trace.csv")))[-1:]:
-    rows = [r for r in csv.DictReader(open(f)) if "lutr::k_" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "lutr::" in r["Kernel_Name"] and "make_lat16" not in r["Kernel_Name"]]
     summary["dispatch_us"] = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1) for r in rows]
 counters = defaultdict(list)
 kernel = None
+# the kernel that carries the launch: the lutr kernel with the most time in the kernel-trace pass (helpers such as the
+# fp16 lattice builder also live in namespace lutr)
+main = None
+if summary.get("kernel_stats"):
+    cand = [k for k in summary["kernel_stats"] if "lutr::" in k["Name"]]
+    if cand:
+        main = max(cand, key=lambda k: float(k["Calls"]) * float(k["AverageNs"]))["Name"].split("(")[0]
+summary["kernel_stats"] = [k for k in summary.get("kernel_stats", [])]
 for sub in ("fetch", "write", "sq", "tcc"):
-    for f in glob.glob(str(src / sub / "*" / "*_counter_collection.csv")):
+    for f in sorted(glob.glob(str(src / sub / "*" / "*_counter_collection.csv")))[-1:]:
         for r in csv.DictReader(open(f)):
-            if "lutr::k_" in r["Kernel_Name"]:
+            if "lutr::" in r["Kernel_Name"] and (main is None or r["Kernel_Name"].startswith(main)):
                 kernel = r["Kernel_Name"].split("(")[0]
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 summary.setdefault("dispatch", {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size",
