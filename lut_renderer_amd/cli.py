@@ -46,6 +46,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("-y", action="store_true", help="overwrite the output (ffmpeg's -y)")
+    ap.add_argument("--duration", type=float, default=None,
+                    help="seconds of video, for the Duration: line when the input is a pipe (-i -) and cannot be measured")
     return ap
 
 
@@ -72,7 +74,14 @@ def main(argv=None) -> int:
     stop = {"flag": False}
     signal.signal(signal.SIGTERM, lambda *_: stop.__setitem__("flag", True))
     try:
-        if os.path.exists(args.output) and not args.y:
+        piped_in, piped_out = args.input == "-", args.output == "-"
+        # with frames on stdout the report goes to stderr (the caller merges the two, task_manager.py:145-151)
+        report = sys.stderr if piped_out else sys.stdout
+
+        def say(text):
+            print(text, file=report, flush=True)
+
+        if not piped_out and os.path.exists(args.output) and not args.y:
             raise FileExistsError(f"{args.output} exists (pass -y to overwrite)")
         plan, kw, w, h = plan_from_args(args)
         from .cube import read_lut
@@ -84,36 +93,54 @@ def main(argv=None) -> int:
         pix_fmt, out_fmt = kw.pop("pix_fmt"), kw.pop("out_pix_fmt")
         pipe = HostPipeline(eng, pix_fmt, w, h, batch=args.batch, out_pix_fmt=out_fmt, **kw)
         fb = pipe.fin.frame_bytes
-        total = os.path.getsize(args.input) // fb
-        if total == 0:
-            raise ValueError(f"{args.input}: no complete {w}x{h} {args.pix_fmt} frame ({fb} bytes each)")
-        print(f"Input #0, rawvideo, from '{args.input}':", flush=True)
-        print(f"  Duration: {_hms(total / args.fps)}, {total} frames, {w}x{h} {args.pix_fmt}", flush=True)
+        if piped_in:
+            total = None if args.duration is None else max(1, int(round(args.duration * args.fps)))
+        else:
+            total = os.path.getsize(args.input) // fb
+            if total == 0:
+                raise ValueError(f"{args.input}: no complete {w}x{h} {args.pix_fmt} frame ({fb} bytes each)")
+        say(f"Input #0, rawvideo, from '{'pipe:0' if piped_in else args.input}':")
+        if total is not None:
+            say(f"  Duration: {_hms(total / args.fps)}, {total} frames, {w}x{h} {args.pix_fmt}")
+        else:
+            say(f"  Duration: N/A, {w}x{h} {args.pix_fmt}")
         for note in plan.notes:
-            print(f"  {note}", flush=True)
+            say(f"  {note}")
         t0 = time.time()
         state = {"done": 0}
-        with open(args.input, "rb") as fi, open(args.output, "wb") as fo:
+        fi = sys.stdin.buffer if piped_in else open(args.input, "rb")
+        fo = sys.stdout.buffer if piped_out else open(args.output, "wb")
+        try:
             def fill(buf, max_frames):
-                got = fi.readinto(memoryview(buf)[: max_frames * fb])
-                return got // fb
+                view, got = memoryview(buf)[: max_frames * fb], 0
+                while got < len(view):                       # a pipe returns short reads: collect the whole batch (or EOF)
+                    n = fi.readinto(view[got:])
+                    if not n:
+                        break
+                    got += n
+                return got // fb                             # a trailing partial frame is dropped
 
             def drain(buf, n):
                 fo.write(memoryview(buf))
                 state["done"] += n
                 el = max(time.time() - t0, 1e-9)
-                print(f"frame={state['done']:6d} fps={state['done'] / el:7.1f} time={_hms(state['done'] / args.fps)}",
-                      flush=True)
+                say(f"frame={state['done']:6d} fps={state['done'] / el:7.1f} time={_hms(state['done'] / args.fps)}")
 
-            pipe.run(fill, drain, total_frames=total, stop=lambda: stop["flag"])
+            pipe.run(fill, drain, total_frames=None if piped_in else total, stop=lambda: stop["flag"])
+            fo.flush()
+        finally:
+            if not piped_in:
+                fi.close()
+            if not piped_out:
+                fo.close()
         eng.close()
         if stop["flag"]:
-            print("Exiting normally, received signal 15.", flush=True)
+            say("Exiting normally, received signal 15.")
             return 255
-        print(f"video: {state['done']} frames written to '{args.output}'", flush=True)
+        say(f"video: {state['done']} frames written to '{'pipe:1' if piped_out else args.output}'")
         return 0
     except Exception as exc:  # the caller only sees text + exit code (task_manager.py:105-112)
-        print(f"Error: {exc}", flush=True)
+        print(f"Error: {exc}", file=sys.stderr if getattr(args, "output", "") == "-" else sys.stdout, flush=True)
         return 1
 
 

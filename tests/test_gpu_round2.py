@@ -368,3 +368,53 @@ def test_small_lattices_are_staged_whole_and_content_stops_mattering(engine, orc
     finally:
         engine.set_precision("strict")
         engine.set_variant("auto")
+
+
+# ------------------------------------------------------------------ decode | engine | encode (pipe.py) with stand-in codecs
+def test_three_process_stage_streams_frames_through_the_engine(orc, cube_dir, tmp_path):
+    """`pipe.run_stage` with `cat` as decoder and encoder (no ffmpeg on this image): frames enter the engine CLI on stdin, leave
+    on stdout, the report (Duration: / time= lines) is relayed for TaskRunner._run_stage, and the bytes equal the oracle's."""
+    import io
+    from lut_renderer_amd.command import engine_command
+    from lut_renderer_amd.params import ProcessingParams, VideoInfo
+    from lut_renderer_amd.pipe import StageCommands, run_stage
+    w, h, nf = 256, 72, 21
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    fr = [frames.natural_yuv(w, h, 10, 1, 1, k=60 + i) for i in range(nf)]
+    raw = tmp_path / "in.yuv"
+    with open(raw, "wb") as f:
+        for planes in fr:
+            for p in planes:
+                f.write(np.ascontiguousarray(p).tobytes())
+    info = VideoInfo(width=w, height=h, bit_depth=10, pix_fmt="yuv420p10le", color_range="tv", colorspace="bt709", fps=25.0,
+                     duration=nf / 25.0)
+    params = ProcessingParams(video_codec="libx264")          # 10-bit source, 8-bit codec: format=yuv420p (App. D case K)
+    out = tmp_path / "out.yuv"
+    eng = engine_command(Path("-"), Path("-"), params, cube_dir / "log709_33.cube", info) + ["--duration", f"{nf / 25.0:.3f}", "--batch", "4"]
+    cmds = StageCommands(["cat", str(raw)], eng, ["sh", "-c", f"cat > '{out}'"], [])
+    log = io.StringIO()
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        rc = run_stage(cmds, out=log)
+    finally:
+        os.chdir(cwd)
+    text = log.getvalue()
+    assert rc == 0, text
+    assert "Duration: 00:00:00.84" in text and "time=00:00:00.84" in text and "LUT: " in text
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", 10, 10, 8, 4)
+    got = np.frombuffer(out.read_bytes(), dtype=np.uint8)
+    fb8 = w * h * 3 // 2
+    assert got.size == nf * fb8
+    for i, planes in enumerate(fr):
+        want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 8, 1, 1, planes)
+        assert np.array_equal(got[i * fb8:(i + 1) * fb8], np.concatenate([p.ravel() for p in want])), f"frame {i}"
+    # a failing stage is reported and fails the whole stage
+    bad = StageCommands(["cat", str(tmp_path / "missing.yuv")], eng, ["sh", "-c", "cat > /dev/null"], [])
+    log2 = io.StringIO()
+    os.chdir(ROOT)
+    try:
+        assert run_stage(bad, out=log2) != 0
+    finally:
+        os.chdir(cwd)
+    assert "decoder exited" in log2.getvalue()

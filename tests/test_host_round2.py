@@ -114,3 +114,27 @@ def test_noise_sweep_distributions():
     for bad in ("noise", "noisex", "noise-4", "plasma"):
         with pytest.raises(ValueError):
             frames.make_yuv(bad, 16, 16, 8, 1, 1)
+
+
+def test_engine_stage_commands_split_build_command_around_the_engine():
+    """decode | engine | encode (pipe.py): the decoder carries the source, the engine the LutPlan, the encoder everything
+    build_command emits except the -vf chain, with the colour tags of the LUT policy (ffmpeg.py:348-383)."""
+    from lut_renderer_amd.pipe import engine_stage_commands
+    params = ProcessingParams(video_codec="libx264", audio_codec="aac", crf="18", preset="slow")
+    info = VideoInfo(width=3840, height=2160, bit_depth=10, pix_fmt="yuv420p10le", color_range="tv", colorspace="bt2020nc",
+                     fps=24.0, duration=12.5)
+    c = engine_stage_commands(Path("in.mov"), Path("out.mp4"), params, Path("look.cube"), info, python_bin="python3")
+    full = build_command(Path("in.mov"), Path("out.mp4"), params, lut_path=Path("look.cube"), source_info=info)
+    assert c.decoder[0] == "ffmpeg" and c.decoder[c.decoder.index("-i") + 1] == "in.mov"
+    assert c.decoder[c.decoder.index("-pix_fmt") + 1] == "yuv420p10le" and c.decoder[-1] == "pipe:1" and "-vf" not in c.decoder
+    assert c.engine[:3] == ["python3", "-m", "lut_renderer_amd.cli"] and c.engine[c.engine.index("-i") + 1] == "-"
+    assert c.engine[c.engine.index("--out-pix-fmt") + 1] == "yuv420p"          # libx264 cannot do 10 bit: App. D case K
+    assert c.engine[c.engine.index("--duration") + 1] == "12.500"
+    e = c.encoder
+    assert "-vf" not in e and e[-1] == "out.mp4" and e[e.index("-i") + 1] == "pipe:0"
+    assert e[e.index("-f") + 1] == "rawvideo" and e[e.index("-s") + 1] == "3840x2160" and e.index("-f") < e.index("-i")
+    assert e[e.index("-pix_fmt") + 1] == "yuv420p"                              # raw input format = what the engine writes
+    for flag in ("-c:v", "-c:a", "-crf", "-preset", "-color_primaries", "-color_trc", "-colorspace", "-color_range"):
+        assert flag in e and e[e.index(flag) + 1] == full[full.index(flag) + 1], flag
+    with pytest.raises(ValueError, match="copy"):
+        engine_stage_commands(Path("a"), Path("b"), ProcessingParams(video_codec="copy"), Path("x.cube"), info)

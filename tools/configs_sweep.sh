@@ -18,16 +18,18 @@ run --size uhd --fmt yuv420p10le --interp tetrahedral --lut 17 --dist uniform --
 run --size uhd --fmt yuv420p10le --out-fmt yuv420p --interp tetrahedral
 run --size uhd --fmt yuv420p10le --range-src pc --interp tetrahedral
 run --size uhd --fmt yuv420p10le --range-src pc --out-fmt yuv420p --interp tetrahedral
-run --size 1080p --fmt yuv420p --interp trilinear --frames 64
+run --size 1080p --fmt yuv420p --interp trilinear --frames 512
+run --size 1080p --fmt yuv420p --interp tetrahedral --frames 512
 run --size 1080p --fmt yuv420p --interp tetrahedral --frames 64
-run --size 8k --fmt yuv420p10le --interp tetrahedral --frames 8
-run --size 8k --fmt yuv420p10le --interp trilinear --frames 8
+run --size 8k --fmt yuv420p10le --interp tetrahedral --frames 64
+run --size 8k --fmt yuv420p10le --interp trilinear --frames 64
 run --size uhd --fmt yuv422p10le --interp tetrahedral
-run --size uhd --fmt yuv444p10le --interp tetrahedral --frames 16
+run --size uhd --fmt yuv444p10le --interp tetrahedral --frames 128
+run --size uhd --fmt gbrp10le --interp tetrahedral --frames 128
 run --size uhd --fmt gbrp10le --interp tetrahedral --frames 16
-run --size uhd --fmt gbrp10le --interp trilinear --frames 16
-run --size uhd --fmt gbrp --interp tetrahedral --frames 32
-run --size uhd --fmt gbrp10le --interp nearest --frames 16
+run --size uhd --fmt gbrp10le --interp trilinear --frames 128
+run --size uhd --fmt gbrp --interp tetrahedral --frames 128
+run --size uhd --fmt gbrp10le --interp nearest --frames 128
 run --size uhd --fmt rgb24 --interp tetrahedral --frames 32
 run --size uhd --fmt rgba --interp tetrahedral --frames 32
 run --size uhd --fmt rgb48le --interp tetrahedral --frames 16
