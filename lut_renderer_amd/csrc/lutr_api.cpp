@@ -321,7 +321,7 @@ int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[8])
     if (out) {
         for (int i = 0; i < 8; i++) out[i] = 0;
         if (c->stats) {
-            unsigned h[12];
+            unsigned h[32];
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
             for (int i = 0; i < 4; i++) out[i] = h[i];
@@ -330,18 +330,22 @@ int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[8])
             out[6] = (uint64_t)h[11] * 64 / 100;                   // summed wave lifetimes, us
             out[7] = h[6];                                          // tiles that needed the second-level (exact) window test
             if (getenv("LUTR_DEBUG"))
-                fprintf(stderr, "[lutr stats raw] %u %u %u %u | %u %u %u | %u %u %u | %u %u\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6],
+            {
+                fprintf(stderr, "[lutr stats raw] %u %u %u %u | %u %u %u | %u %u %u | %u %u |", h[0], h[1], h[2], h[3], h[4], h[5], h[6],
                         h[7], h[8], h[9], h[10], h[11]);
+                for (int i = 12; i < 32; i++) fprintf(stderr, " %u", h[i]);
+                fprintf(stderr, "\n");
+            }
         }
     }
     if (enable && !c->stats) {
-        HIP_TRY(hipMalloc((void **)&c->stats, 12 * sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void **)&c->stats, 32 * sizeof(unsigned)));
     } else if (!enable && c->stats) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(c->stats);
         c->stats = nullptr;
     }
-    if (c->stats) HIP_TRY(hipMemset(c->stats, 0, 12 * sizeof(unsigned)));
+    if (c->stats) HIP_TRY(hipMemset(c->stats, 0, 32 * sizeof(unsigned)));
     return LUTR_OK;
 }
 

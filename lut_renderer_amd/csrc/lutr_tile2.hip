@@ -52,6 +52,9 @@
 #ifndef LUTR_T2_WAVES_PER_EU
 #define LUTR_T2_WAVES_PER_EU 4
 #endif
+#ifndef LUTR_T2_PIN
+#define LUTR_T2_PIN 2             // wave-uniform constants copied to VGPRs: 1-2 kernel-wide (Y rows), 3-4 per tile (window, chroma rows)
+#endif
 #ifndef LUTR_T2_PHASES
 #define LUTR_T2_PHASES 1          // scheduling barriers between the load and use phases of a pixel group (tile_body)
 #endif
@@ -167,6 +170,19 @@ DEV Crd crd_compute(const LutConsts &L, float code, float sc)
 DEV Crd crd_table(unsigned idx)
 {
     const float2 e = *(const float2 *)(smem + idx * 8u);
+    return Crd{e.x, e.y};
+}
+// The per-pixel paths index the table by BYTE offset: their YUV -> RGB constants are pre-multiplied by 8 (KB in the kernel;
+// a power of two commutes with every rounding), so (unsigned)(8 * v) & ~7 == 8 * floor(v): the `* 8` that was a
+// quarter-rate v_lshl_add_u32 per channel is a v_and_b32 on the other pipe.
+// The table sits at LDS address 0 (the kernel has no static LDS, the dynamic block starts at 0 -- checked at kernel start):
+// the offset IS the address, no v_add of the block's base.
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f2v *lds_f2p;
+typedef __attribute__((address_space(3))) const float *lds_fp;
+DEV Crd crd_table8(unsigned off)
+{
+    const f2v e = *(lds_f2p)(uintptr_t)off;
     return Crd{e.x, e.y};
 }
 
@@ -381,10 +397,10 @@ DEV Bnd tile_bounds(const LutConsts &L, const YuvConsts &K, const Geom &TG, Tile
             if constexpr (PRE) yv = cfloor(fma_(K.py, yv, K.pyb), K.pre_max);
             const float yy = fma_(K.ky, yv, K.yb);
             if constexpr (V >= V_TAB) {
-                const unsigned top = (unsigned)(TG.tab_entries - 1);          // raw codes are unvetted here
-                pr[q] = *(const float *)(smem + min((unsigned)(yy + rv), top) * 8u);
-                pg_[q] = *(const float *)(smem + min((unsigned)(yy + gv), top) * 8u);
-                pb_[q] = *(const float *)(smem + min((unsigned)(yy + bu), top) * 8u);
+                // K is the kernel's KB; the caller has checked that every raw code is legal, so the padded table covers the sums
+                pr[q] = *(lds_fp)(uintptr_t)((unsigned)(yy + rv) & ~7u);
+                pg_[q] = *(lds_fp)(uintptr_t)((unsigned)(yy + gv) & ~7u);
+                pb_[q] = *(lds_fp)(uintptr_t)((unsigned)(yy + bu) & ~7u);
             } else {
                 pr[q] = crd_compute<INTERP>(L, cfloor(yy + rv, K.max_l), L.sc[0]).p;
                 pg_[q] = crd_compute<INTERP>(L, cfloor(yy + gv, K.max_l), L.sc[1]).p;
@@ -449,7 +465,7 @@ template <int WIN> DEV uint32_t pack_hi(int v) { const uint32_t h = WIN ? (uint3
 // boxes around this tile's raw extremes whose conservative cell map lies inside the window's cell ranges.  Called with
 // back-off (1st, 4th, 16th consecutive second-level pass), so a wave leaves the expensive mode once it is past the edge.
 template <int WIN, int INTERP, int PRE, int V>
-DEV void rebox(const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext &e_, int scratch_off, int lane)
+DEV bool rebox(const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext &e_, int scratch_off, int lane)
 {
     Ext e = e_;
     asm volatile("" : "+v"(e.ymin), "+v"(e.ymax), "+v"(e.cbmin), "+v"(e.cbmax), "+v"(e.crmin), "+v"(e.crmax));
@@ -484,9 +500,10 @@ DEV void rebox(const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext
                 bx.crlo = pack_lo<WIN>(tcr0); bx.crhi = pack_hi<WIN>(tcr1);
                 box_store(scratch_off, bx);
             }
-            return;
+            return true;
         }
     }
+    return false;
 }
 
 // Neither test vouches for the tile: stage a new window around the tile's EXACT cells (spare cells on the two
@@ -525,6 +542,8 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
     const int unit = (mr + 1) >> 8;                                            // one 8-bit code in raw codes
     // (1) A window that covers the conservative image of the tile's raw box plus a margin: the tiles that follow then pass
     //     the cheap first-level test.  Margins from generous to none; the first whose cells fit the capacity wins.
+    // (Measured: 95 % of the tiles that leave a raw box leave it through a chroma bound -- vertical colour edges that a
+    // 256-px-wide tile straddles for a whole chunk.  Trading luma room for 4-6 codes of chroma margin did not pay: -0.5 %.)
 #pragma unroll 1
     for (int t = 0; t < 4 && !placed; t++) {
         const int mc = t == 0 ? 2 * unit : (t == 1 ? unit : (t == 2 ? (unit + 3) / 4 : 0));
@@ -581,25 +600,25 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
 
     const int n1 = L.n1, nmax = L.n1 - 1;
     const int plane = ng * nb, total = nr * plane;
-    // i -> (ir, ig, ib): floor(i/d) = umulhi(i, ceil(2^32/d)), exact while i*d < 2^32 (i < 32768, d <= 16641)
-    const unsigned inv_plane = (unsigned)((0x100000000ull + plane - 1) / plane);
-    const unsigned inv_nb = (unsigned)((0x100000000ull + nb - 1) / nb);
+    // i -> (ir, ig, ib) by float reciprocals: floor(i / d) == (int)((i + 0.5) * (1 / d)) while the quotient stays below 2^7 and
+    // d below 2^12 (error of the product < 2^-16, distance of (i + 0.5) / d from an integer >= 2^-13; d <= window capacity); every product fits 24 bits
+    const float rcp_plane = 1.0f / (float)plane, rcp_nb = 1.0f / (float)nb;
     // Batches of kB nodes per lane: all kB global reads are issued before the first LDS write, so a restage costs about
     // one L2 round trip per batch instead of one per node (the wave is stalled meanwhile; 4 waves per SIMD cannot hide it).
-    constexpr int kB = 6;
+    constexpr int kB = LUTR_T2_KB_FAST > 0 && N::fast ? LUTR_T2_KB_FAST : 6;
     for (int base = 0; base < total; base += 64 * kB) {
         int dst[kB];
         typename std::conditional<N::fast, uint2, float4>::type val[kB];
 #pragma unroll
         for (int k = 0; k < kB; k++) {
             const int i = min(base + k * 64 + lane, total - 1);              // the last batch re-reads the final node: harmless
-            const int ir = (int)__umulhi((unsigned)i, inv_plane), rem = i - ir * plane;
-            const int ig = (int)__umulhi((unsigned)rem, inv_nb), ib = rem - ig * nb;
+            const int ir = (int)(((float)i + 0.5f) * rcp_plane), rem = i - __mul24(ir, plane);
+            const int ig = (int)(((float)rem + 0.5f) * rcp_nb), ib = rem - __mul24(ig, nb);
             int r = r0 + ir, g = r + g0 + ig, b = r + b0 + ib;
             // nodes outside the cube are never referenced by a valid pixel: clamp to stay inside the lattice
             r = min(max(r, 0), nmax); g = min(max(g, 0), nmax); b = min(max(b, 0), nmax);
-            const int src = (r * n1 + g) * n1 + b;
-            dst[k] = slice_off + kLN * (ir * sr + ig * nb + ib);
+            const int src = __mul24(__mul24(r, n1) + g, n1) + b;
+            dst[k] = slice_off + kLN * (__mul24(ir, sr) + __mul24(ig, nb) + ib);
             if constexpr (N::fast) val[k] = L.lat16[src];
             else val[k] = L.lat[src];
         }
@@ -820,12 +839,13 @@ DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, co
         const float yy = fma_(K.ky, yv, K.yb);
         if constexpr (V >= V_TAB) {
             // clip(floor(v), 0, M): v_cvt_u32_f32 floors and saturates negatives to 0; the table is padded past M
-            unsigned ri = (unsigned)(yy + rv[c]), gi = (unsigned)(yy + gv[c]), bi = (unsigned)(yy + bu[c]);
+            // K is the kernel's KB here: sums are 8 x the code, the masked conversion is the table's byte offset
+            unsigned ri = (unsigned)(yy + rv[c]) & ~7u, gi = (unsigned)(yy + gv[c]) & ~7u, bi = (unsigned)(yy + bu[c]) & ~7u;
             if constexpr (!LDS) {           // the gather body also serves tiles with raw codes nobody vouched for
-                const unsigned top = (unsigned)(TG.tab_entries - 1);
+                const unsigned top = (unsigned)(TG.tab_entries - 1) * 8u;
                 ri = min(ri, top); gi = min(gi, top); bi = min(bi, top);
             }
-            q.r[p] = crd_table(ri); q.g[p] = crd_table(gi); q.b[p] = crd_table(bi);
+            q.r[p] = crd_table8(ri); q.g[p] = crd_table8(gi); q.b[p] = crd_table8(bi);
         } else {
             const float rq = cfloor(yy + rv[c], K.max_l), gq = cfloor(yy + gv[c], K.max_l), bq = cfloor(yy + bu[c], K.max_l);
             q.r[p] = crd_compute<INTERP>(L, rq, L.sc[0]); q.g[p] = crd_compute<INTERP>(L, gq, L.sc[1]);
@@ -836,6 +856,15 @@ DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, co
 
 #ifndef LUTR_T2_PIPE
 #define LUTR_T2_PIPE 1            // software pipeline across pixel groups: group g+1's coordinate reads are issued before group g's blend
+#endif
+#ifndef LUTR_T2_FENCE_ALL
+#define LUTR_T2_FENCE_ALL 0
+#endif
+#ifndef LUTR_T2_PIPE_FAST
+#define LUTR_T2_PIPE_FAST 0
+#endif
+#ifndef LUTR_T2_KB_FAST
+#define LUTR_T2_KB_FAST 0         // nodes per lane and batch when a fast (8-byte node) window is staged; 0 = as the strict kernels (6)
 #endif
 #ifndef LUTR_T2_TB_FAST
 #define LUTR_T2_TB_FAST 4
@@ -849,16 +878,29 @@ DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, co
 // sched_barrier keeps the machine scheduler from sinking the reads back next to their uses; the zero-instruction
 // fences at the end of a group keep instruction selection from hoisting every group to the top (> 1000 spilled registers).
 template <bool LDS, int WIN, int WOUT, int CSX, int CSY, int INTERP, int PRE, int V>
-DEV void tile_body(const LutConsts &L, const YuvConsts &K, const Win &W, const Geom &TG, TileIn<WIN, WOUT, CSX, CSY> &in,
+DEV void tile_body(const LutConsts &L, const YuvConsts &K_, const Win &W_, const Geom &TG, TileIn<WIN, WOUT, CSX, CSY> &in,
                    TileOut<WIN, WOUT, CSX, CSY> &out)
 {
+    // the four address factors go to VGPRs for the length of the tile (three fma per pixel at full rate instead of the
+    // SGPR-operand rate); kernel-wide they would be live across the restage code, which has no registers to spare
+    Win W = W_;
+    if constexpr (LDS && LUTR_T2_PIN >= 3 && V == V_FAST && INTERP != LUTR_INTERP_TRILINEAR) {
+        W.fr = in_vgpr(W_.fr); W.fg = in_vgpr(W_.fg); W.fb = in_vgpr(W_.fb); W.fc = in_vgpr(W_.fc);
+    }
+    YuvConsts K = K_;
+    if constexpr (LDS && LUTR_T2_PIN >= 4 && V == V_FAST && INTERP != LUTR_INTERP_TRILINEAR) {
+        // the chroma terms and the RGB -> CbCr rows: 12 moves per tile buy 3 full-rate ops per pixel
+        K.krv = in_vgpr(K_.krv); K.kgu = in_vgpr(K_.kgu); K.kgv = in_vgpr(K_.kgv); K.kbu = in_vgpr(K_.kbu); K.coff = in_vgpr(K_.coff);
+        K.cbr = in_vgpr(K_.cbr); K.cbg = in_vgpr(K_.cbg); K.cbb = in_vgpr(K_.cbb); K.cob = in_vgpr(K_.cob);
+        K.crr = in_vgpr(K_.crr); K.crg = in_vgpr(K_.crg); K.crb = in_vgpr(K_.crb);
+    }
     using T = Tile<WIN, WOUT, CSX, CSY>;
     // a group = 4 pixels: all BH rows of GW columns; it owns NCG chroma samples
     constexpr int GW = 4 / T::BH, NG = T::PXT / GW, NCG = (GW >> CSX) > 0 ? (GW >> CSX) : 1;
     constexpr bool kDead = V >= V_UNIT;          // launcher checked the RGB->YUV maxima too (out_clip_dead)
     // measured (UHD yuv420p10le tetrahedral, Gpx/s): strict 503 with the pipeline, 484 without; fast 458 with (the extra live
     // coordinates push its 4-pixel tap batches into spills), 550-565 without
-    constexpr bool kPipe = LUTR_T2_PIPE && LDS && V >= V_TAB && V != V_FAST;
+    constexpr bool kPipe = LUTR_T2_PIPE && LDS && V >= V_TAB && (V != V_FAST || LUTR_T2_PIPE_FAST);
     constexpr int TB = INTERP == LUTR_INTERP_TRILINEAR ? (V == V_FAST ? 2 : 1)
                                                        : (INTERP == LUTR_INTERP_NEAREST ? 4 : (V == V_FAST ? LUTR_T2_TB_FAST : 2));
     GroupCrd cq[2];
@@ -904,12 +946,38 @@ DEV void tile_body(const LutConsts &L, const YuvConsts &K, const Win &W, const G
             wput<WOUT>(out.cb, j, ofloor<kDead>(fma_(K.cbr, rs[c], fma_(K.cbg, gs[c], fma_(K.cbb, bs[c], K.cob))), K.max_o));
             wput<WOUT>(out.cr, j, ofloor<kDead>(fma_(K.crr, rs[c], fma_(K.crg, gs[c], fma_(K.crb, bs[c], K.cob))), K.max_o));
         }
+#if LUTR_T2_FENCE_ALL
         fence_words<T::YWI * T::BH>(&in.y[0][0]);
         fence_words<T::CWI>(in.cb);
         fence_words<T::CWI>(in.cr);
         fence_words<T::YWO * T::BH>(&out.y[0][0]);
         fence_words<T::CWO>(out.cb);
         fence_words<T::CWO>(out.cr);
+#else
+        // Only what is live anyway: the input words later groups still read (they cannot start before this point) and the
+        // output words this group wrote (it cannot finish after it).  Fencing consumed input words or unborn output words
+        // would keep 2 x 12 registers allocated through the whole tile.
+        if (g + 1 < NG) {
+            constexpr int ISH = WIN ? 1 : 2;
+            const int y0 = ((g + 1) * GW) >> ISH, c0 = ((g + 1) * NCG) >> ISH;
+#pragma unroll
+            for (int dy = 0; dy < T::BH; dy++)
+#pragma unroll
+                for (int k = 0; k < T::YWI; k++) if (k >= y0) fence_words<1>(&in.y[dy][k]);
+#pragma unroll
+            for (int k = 0; k < T::CWI; k++) if (k >= c0) { fence_words<1>(&in.cb[k]); fence_words<1>(&in.cr[k]); }
+        }
+        {
+            constexpr int OSH = WOUT ? 1 : 2;
+            const int y0 = (g * GW) >> OSH, y1 = ((g + 1) * GW - 1) >> OSH, c0 = (g * NCG) >> OSH, c1 = ((g + 1) * NCG - 1) >> OSH;
+#pragma unroll
+            for (int dy = 0; dy < T::BH; dy++)
+#pragma unroll
+                for (int k = 0; k < T::YWO; k++) if (k >= y0 && k <= y1) fence_words<1>(&out.y[dy][k]);
+#pragma unroll
+            for (int k = 0; k < T::CWO; k++) if (k >= c0 && k <= c1) { fence_words<1>(&out.cb[k]); fence_words<1>(&out.cr[k]); }
+        }
+#endif
     }
 }
 
@@ -951,13 +1019,17 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     YuvConsts K = K_;
     // a wave-uniform constant used by several VALU ops per pixel is worth a VGPR (an SGPR operand halves the issue rate
     // of plain fp32 ops on gfx950, tools/ubench); the trilinear bodies have no registers to spare
-#ifndef LUTR_T2_PIN
-#define LUTR_T2_PIN 2
-#endif
     if constexpr (INTERP != LUTR_INTERP_TRILINEAR && LUTR_T2_PIN >= 1) {
         K.cyr = in_vgpr(K_.cyr); K.cyg = in_vgpr(K_.cyg); K.cyb = in_vgpr(K_.cyb);
         if constexpr (LUTR_T2_PIN >= 2) { K.ky = in_vgpr(K_.ky); K.yb = in_vgpr(K_.yb); K.yob = in_vgpr(K_.yob); }
         if constexpr (!N::fast) L.maxf = in_vgpr(L_.maxf);
+    }
+    if (lds_base() != 0) __builtin_trap();        // crd_table8 addresses the table absolutely
+    // the per-pixel constants of the table variants, times 8 (crd_table8); map_box keeps the plain ones
+    YuvConsts KB = K;
+    if constexpr (V >= V_TAB) {
+        KB.ky = K.ky * 8.0f; KB.yb = K.yb * 8.0f;
+        KB.krv = K.krv * 8.0f; KB.kgu = K.kgu * 8.0f; KB.kgv = K.kgv * 8.0f; KB.kbu = K.kbu * 8.0f;
     }
     if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier ...
     if (TG.whole) {                                                             // ... but for this one, in whole-lattice mode
@@ -1000,18 +1072,41 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     }
     constexpr int YIB = T::YWI * 4, YOB = T::YWO * 4, CIB = T::CWI * 4, COB = T::CWO * 4;
 
-    // Input words of a tile.  Idle lanes of edge tiles re-read a valid unit of the same tile.
-    auto load_tile = [&](TileIn<WIN, WOUT, CSX, CSY> &dst, int f, int tsx, int try_) {
-        const int lxc = min(lx, TG.uw - 1 - tsx * lw), lyc = min(ly, TG.urows - 1 - (try_ << lh_log2));
+    // Where a tile lives: wave-uniform strip pointers (frame, strip and unit row folded in) plus the clamps for lanes past
+    // the right / bottom edge.  Built from scratch when a chunk is claimed; inside a chunk the next tile is one step down,
+    // i.e. six 64-bit scalar adds -- recomputing the 64-bit products per tile cost ~140 scalar instructions per tile and wave.
+    struct TilePos { const uint8_t *s0, *s1, *s2; uint8_t *d0, *d1, *d2; int xlim, ylim; };
+    const unsigned ystep_s0 = (unsigned)((T::BH << lh_log2) * (int)P.ss[0]), ystep_s1 = (unsigned)((int)P.ss[1] << lh_log2),
+                   ystep_s2 = (unsigned)((int)P.ss[2] << lh_log2);
+    const unsigned ystep_d0 = (unsigned)((T::BH << lh_log2) * (int)P.ds[0]), ystep_d1 = (unsigned)((int)P.ds[1] << lh_log2),
+                   ystep_d2 = (unsigned)((int)P.ds[2] << lh_log2);
+    auto pos_at = [&](int f, int tsx, int try_) {
+        TilePos q;
         const long long urow0 = cr0 + (try_ << lh_log2);                  // wave-uniform
-        const uint8_t *sy = P.s[0] + f * P.sfs[0] + urow0 * T::BH * (long long)P.ss[0] + (long long)tsx * lw * YIB;
-        const uint8_t *scb = P.s[1] + f * P.sfs[1] + urow0 * (long long)P.ss[1] + (long long)tsx * lw * CIB;
-        const uint8_t *scr = P.s[2] + f * P.sfs[2] + urow0 * (long long)P.ss[2] + (long long)tsx * lw * CIB;
+        q.s0 = P.s[0] + f * P.sfs[0] + urow0 * T::BH * (long long)P.ss[0] + (long long)tsx * lw * YIB;
+        q.s1 = P.s[1] + f * P.sfs[1] + urow0 * (long long)P.ss[1] + (long long)tsx * lw * CIB;
+        q.s2 = P.s[2] + f * P.sfs[2] + urow0 * (long long)P.ss[2] + (long long)tsx * lw * CIB;
+        q.d0 = P.d[0] + f * P.dfs[0] + urow0 * T::BH * (long long)P.ds[0] + (long long)tsx * lw * YOB;
+        q.d1 = P.d[1] + f * P.dfs[1] + urow0 * (long long)P.ds[1] + (long long)tsx * lw * COB;
+        q.d2 = P.d[2] + f * P.dfs[2] + urow0 * (long long)P.ds[2] + (long long)tsx * lw * COB;
+        q.xlim = TG.uw - 1 - tsx * lw;
+        q.ylim = TG.urows - 1 - (try_ << lh_log2);
+        return q;
+    };
+    auto pos_down = [&](TilePos &q) {
+        q.s0 += ystep_s0; q.s1 += ystep_s1; q.s2 += ystep_s2;
+        q.d0 += ystep_d0; q.d1 += ystep_d1; q.d2 += ystep_d2;
+        q.ylim -= 1 << lh_log2;
+    };
+    // Input words of a tile.  Idle lanes of edge tiles re-read a valid unit of the same tile.  32-bit lane offsets: the
+    // launcher only sends strides below 2^24 (a tile spans at most 128 rows).
+    auto load_tile = [&](TileIn<WIN, WOUT, CSX, CSY> &dst, const TilePos &q) {
+        const unsigned lxc = (unsigned)min(lx, q.xlim), lyc = (unsigned)min(ly, q.ylim);
+        const unsigned y0 = __umul24(lyc * T::BH, P.ss[0]) + lxc * YIB;
 #pragma unroll
-        for (int dy = 0; dy < T::BH; dy++)
-            ldw<T::YWI>(dst.y[dy], sy + (unsigned)((lyc * T::BH + dy) * (int)P.ss[0] + lxc * YIB));
-        ldw<T::CWI>(dst.cb, scb + (unsigned)(lyc * (int)P.ss[1] + lxc * CIB));
-        ldw<T::CWI>(dst.cr, scr + (unsigned)(lyc * (int)P.ss[2] + lxc * CIB));
+        for (int dy = 0; dy < T::BH; dy++) ldw<T::YWI>(dst.y[dy], q.s0 + (y0 + dy * P.ss[0]));
+        ldw<T::CWI>(dst.cb, q.s1 + (__umul24(lyc, P.ss[1]) + lxc * CIB));
+        ldw<T::CWI>(dst.cr, q.s2 + (__umul24(lyc, P.ss[2]) + lxc * CIB));
     };
 
     bool have_win = false;
@@ -1023,38 +1118,35 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     unsigned st_tiles = 0;
 #define T2_COUNT(i) do { if (counting && lane == 0) cnt[i] += 1u; } while (0)
 #ifdef LUTR_T2_DEBUG_STATS
-    unsigned tk_head = 0, tk_l2 = 0, tk_rest = 0, tk_body = 0, tk_gath = 0, tk_store = 0;
+    unsigned tk_head = 0, tk_l2 = 0, tk_rest = 0, tk_body = 0, tk_gath = 0, tk_store = 0, tk_wait = 0;
     unsigned long long tk = __builtin_amdgcn_s_memrealtime();
 #define TK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); acc += (unsigned)(now_ - tk); tk = now_; }
 #else
 #define TK(acc)
 #endif
-#ifndef LUTR_T2_PREFETCH
-#define LUTR_T2_PREFETCH 1
-#endif
-#if LUTR_T2_PREFETCH
+    TilePos np = pos_at(fr, sx, ry);          // the tile being fetched
     TileIn<WIN, WOUT, CSX, CSY> nxt;
-    load_tile(nxt, fr, sx, ry);
-#endif
+    load_tile(nxt, np);
     for (bool more = true; more;) {
-#if LUTR_T2_PREFETCH
         TileIn<WIN, WOUT, CSX, CSY> in = nxt;
-#else
-        TileIn<WIN, WOUT, CSX, CSY> in;
-        load_tile(in, fr, sx, ry);
-#endif
-        const int cfr = fr, csx = sx, cry = ry;
+        const TilePos cp = np;                // the tile being computed (its store pointers and clamps)
         // Next tile: the one below in this chunk, else the first tile of a newly claimed chunk.  Its loads are issued
         // NOW, before this tile's stores (vmcnt retires in order).  When the queue is drained the current tile is simply
         // fetched again, so every path has the same number of memory operations in flight.
-        if (--rem > 0) ry++;
-        else more = claim_chunk(TG, lane, fr, sx, ry, rem, first);
-#if LUTR_T2_PREFETCH
-        load_tile(nxt, fr, sx, ry);
-#endif
+        if (--rem > 0) { ry++; pos_down(np); }
+        else {
+            more = claim_chunk(TG, lane, fr, sx, ry, rem, first);
+            if (more) np = pos_at(fr, sx, ry);
+        }
+        load_tile(nxt, np);
 
 #ifndef LUTR_T2_EXP
-#define LUTR_T2_EXP 0             // timing experiments only (wrong pixels): 1 = trust the first window forever, 2 = + no stores, 3 = no body
+#define LUTR_T2_EXP 0             // timing experiments only (wrong pixels): 1 = trust the first window forever, 2 = + no stores, 3 = no body, 5.. = body repeated
+#endif
+#ifdef LUTR_T2_DEBUG_STATS
+        TK(tk_store)                 // issuing the next tile's loads counts as store/loop time
+        fence_words<T::YWI * T::BH>(&in.y[0][0]); fence_words<T::CWI>(in.cb); fence_words<T::CWI>(in.cr);
+        TK(tk_wait)                  // ... and this is the wait for this tile's own loads
 #endif
         const Ext e = extremes<WIN, WOUT, CSX, CSY>(in);
         bool use_lds = box_holds(scratch_off, e);             // first level: raw extremes against the window's raw box
@@ -1066,20 +1158,50 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             const uint32_t top = pack_hi<WIN>(TG.max_raw);
             use_lds = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
         } else if (use_lds) {
+#ifdef LUTR_T2_DEBUG_STATS
+            if (l2run > 0 && lane == 0) atomicAdd(&TG.stats[21 + (l2run <= 1 ? 0 : l2run <= 2 ? 1 : l2run <= 4 ? 2 : l2run <= 8 ? 3 : l2run <= 16 ? 4 : 5)], (unsigned)l2run);
+#endif
             l2run = 0;
         } else {
             T2_COUNT(0);
+#ifdef LUTR_T2_DEBUG_STATS
+            {   // which bound of the raw box failed (wave-wide), and was there a box at all
+                const uint4 p = *(const uint4 *)(smem + scratch_off + 32);
+                const uint2 q = *(const uint2 *)(smem + scratch_off + 48);
+                const bool f0 = !__all(pk_subsat(p.x, e.ymin) == 0u), f1 = !__all(pk_subsat(e.ymax, p.y) == 0u);
+                const bool f2 = !__all(pk_subsat(p.z, e.cbmin) == 0u), f3 = !__all(pk_subsat(e.cbmax, p.w) == 0u);
+                const bool f4 = !__all(pk_subsat(q.x, e.crmin) == 0u), f5 = !__all(pk_subsat(e.crmax, q.y) == 0u);
+                if (lane == 0) {
+                    if (p.x > p.y) atomicAdd(&TG.stats[18], 1u);          // empty box
+                    else {
+                        if (f0) atomicAdd(&TG.stats[12], 1u); if (f1) atomicAdd(&TG.stats[13], 1u);
+                        if (f2) atomicAdd(&TG.stats[14], 1u); if (f3) atomicAdd(&TG.stats[15], 1u);
+                        if (f4) atomicAdd(&TG.stats[16], 1u); if (f5) atomicAdd(&TG.stats[17], 1u);
+                        if ((f0 || f1) && !(f2 || f3 || f4 || f5)) atomicAdd(&TG.stats[19], 1u);   // luma only
+                        if (!(f0 || f1) && (f2 || f3 || f4 || f5)) atomicAdd(&TG.stats[20], 1u);   // chroma only
+                    }
+                }
+            }
+#endif
 
-            const Bnd bn = tile_bounds<WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, TG, in);
-            // second level: exact cells against the window's cell ranges (raw codes must be legal for the clamp-free body)
+            // second level: exact cells against the window's cell ranges.  Raw codes must be legal (<= 2^din - 1) for the
+            // clamp-free table reads of tile_bounds and of the LDS body; a tile with wild container values takes the gather body.
             const uint32_t top = pack_hi<WIN>(TG.max_raw);
             const bool legal = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
+            Bnd bn;
+            bn.rmin = bn.gmin = bn.bmin = 1e9f; bn.rmax = bn.gmax = bn.bmax = -1e9f;
+            if (legal) bn = tile_bounds<WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, TG, in);
             use_lds = have_win && legal && cells_hold(scratch_off, bn);
             TK(tk_l2)
             if (use_lds) {
                 l2run++;
+                // back-off: the 1st, 4th, 16th consecutive pass tries to give the window a raw box again.  (Staging a boxed window
+                // instead when that fails was measured: such streaks sit on vertical colour edges, where no box fits: -0.7 %.)
                 if (l2run == 1 || l2run == 4 || l2run == 16) rebox<WIN, INTERP, PRE, V>(L, K, TG, e, scratch_off, lane);
             } else {
+#ifdef LUTR_T2_DEBUG_STATS
+                if (l2run > 0 && lane == 0) atomicAdd(&TG.stats[21 + (l2run <= 1 ? 0 : l2run <= 2 ? 1 : l2run <= 4 ? 2 : l2run <= 8 ? 3 : l2run <= 16 ? 4 : 5)], (unsigned)l2run);
+#endif
                 l2run = 0;
             }
             if (!use_lds) {
@@ -1099,24 +1221,26 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             for (int k = 0; k < T::CWO; k++) { out.cb[k] = in.cb[k % T::CWI]; out.cr[k] = in.cr[k % T::CWI]; }
         } else
         if (use_lds) {
-            tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out); TK(tk_body)
-            if (LUTR_T2_EXP == 4) tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out);
+            tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out); TK(tk_body)
+            if constexpr (LUTR_T2_EXP >= 5) {      // the body again, EXP - 4 times, on inputs the compiler cannot tell are the same
+#pragma unroll 1
+                for (int rep = 0; rep < LUTR_T2_EXP - 4; rep++) {
+                    fence_words<T::YWI * T::BH>(&in.y[0][0]); fence_words<T::CWI>(in.cb); fence_words<T::CWI>(in.cr);
+                    tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out);
+                }
+            }
         }
-        else { tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, K, W, TG, in, out); T2_COUNT(8); TK(tk_gath) }
+        else { tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out); T2_COUNT(8); TK(tk_gath) }
         {
             // Idle lanes of edge tiles processed a duplicate of a valid unit of this tile (load_tile clamps), so they
             // store the same bytes to the same place as its owner: no branch, fixed store count.
-            const int lxc = min(lx, TG.uw - 1 - csx * lw), lyc = min(ly, TG.urows - 1 - (cry << lh_log2));
-            const long long urow0 = cr0 + (cry << lh_log2);
-            uint8_t *dy_ = P.d[0] + cfr * P.dfs[0] + urow0 * T::BH * (long long)P.ds[0] + (long long)csx * lw * YOB;
-            uint8_t *dcb = P.d[1] + cfr * P.dfs[1] + urow0 * (long long)P.ds[1] + (long long)csx * lw * COB;
-            uint8_t *dcr = P.d[2] + cfr * P.dfs[2] + urow0 * (long long)P.ds[2] + (long long)csx * lw * COB;
+            const unsigned lxc = (unsigned)min(lx, cp.xlim), lyc = (unsigned)min(ly, cp.ylim);
+            const unsigned y0 = __umul24(lyc * T::BH, P.ds[0]) + lxc * YOB;
             if (LUTR_T2_EXP != 2 || out.cb[0] == 0x12345u) {
 #pragma unroll
-            for (int dy = 0; dy < T::BH; dy++)
-                stw<T::YWO>(dy_ + (unsigned)((lyc * T::BH + dy) * (int)P.ds[0] + lxc * YOB), out.y[dy]);
-            stw<T::CWO>(dcb + (unsigned)(lyc * (int)P.ds[1] + lxc * COB), out.cb);
-            stw<T::CWO>(dcr + (unsigned)(lyc * (int)P.ds[2] + lxc * COB), out.cr);
+            for (int dy = 0; dy < T::BH; dy++) stw<T::YWO>(cp.d0 + (y0 + dy * P.ds[0]), out.y[dy]);
+            stw<T::CWO>(cp.d1 + (__umul24(lyc, P.ds[1]) + lxc * COB), out.cb);
+            stw<T::CWO>(cp.d2 + (__umul24(lyc, P.ds[2]) + lxc * COB), out.cr);
             }
         }
         TK(tk_store)
@@ -1124,7 +1248,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
 #ifdef LUTR_T2_DEBUG_STATS
     if (TG.stats && lane == 0) {
         atomicAdd(&TG.stats[4], tk_head >> 4); atomicAdd(&TG.stats[5], tk_l2 >> 4); atomicAdd(&TG.stats[7], tk_rest >> 4);
-        atomicAdd(&TG.stats[8], tk_body >> 4); atomicAdd(&TG.stats[9], tk_gath >> 4); atomicAdd(&TG.stats[10], tk_store >> 4);
+        atomicAdd(&TG.stats[11], tk_wait >> 4); atomicAdd(&TG.stats[8], tk_body >> 4); atomicAdd(&TG.stats[9], tk_gath >> 4); atomicAdd(&TG.stats[10], tk_store >> 4);
     }
 #endif
     if (TG.stats && lane == 0) {
@@ -1217,7 +1341,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     if (mode == LUTR_INTERP_NEAREST && pre) return nullptr;
     const int vv = (mode == LUTR_INTERP_NEAREST && v == V_FAST) ? V_UNIT : v;
     for (int i = 0; i < 3; i++)
-        if (P.sfs[i] < 0 || P.dfs[i] < 0) return nullptr;
+        if (P.sfs[i] < 0 || P.dfs[i] < 0 || P.ss[i] < 0 || P.ds[i] < 0 || P.ss[i] >= (1 << 24) || P.ds[i] >= (1 << 24)) return nullptr;
 
     Geom tg;
     const int uw = G.w / pxt, urows = G.rows >> csy;

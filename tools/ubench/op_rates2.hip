@@ -60,6 +60,9 @@ __global__ __launch_bounds__(256) void k_##NAME(float *out, unsigned long long *
 #define A_CMP(x)     asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %1" : : "v"(x), "v"(a) : "s20", "s21");
 #define A_CMPVCC(x)  asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1" : : "v"(x), "v"(a) : "vcc");
 #define A_MOV(x)     asm volatile("v_mov_b32_e32 %0, %1" : "=v"(x) : "v"(a));
+#define A_MULCLAMP(x) asm volatile("v_mul_f32_e64 %0, %0, %1 clamp" : "+v"(x) : "v"(a));
+#define A_FMACLAMP(x) asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(x) : "v"(a), "v"(b));
+#define A_MULNEG(x)  asm volatile("v_mul_f32_e64 %0, -%0, |%1|" : "+v"(x) : "v"(a));
 #define A_RDLANE(x)  asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(x) : "s20");
 #define A_WRLANE(x)  asm volatile("v_writelane_b32 %0, s20, 3" : "+v"(x) : : );
 // mixes: is a slow-class op hidden behind fast-class ones (two pipes) or do the costs add?
@@ -69,6 +72,16 @@ __global__ __launch_bounds__(256) void k_##NAME(float *out, unsigned long long *
 #define A_MIX_FMA_MED3(x)  A_FMA(x) A_MED3(x)
 #define A_MIX_CVT_MED3(x)  A_CVTU(x) A_MED3(x)
 #define A_MIX_FMA_LSHL(x)  A_FMA(x) A_LSHL(x)
+#define A_ADDU(x)    asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(x) : "v"(a));
+#define A_MIX_CVT_AND(x)   A_CVTU(x) A_AND(x)
+#define A_MIX_CVT_LSHL(x)  A_CVTU(x) A_LSHL(x)
+#define A_MIX_CVT_ADDU(x)  A_CVTU(x) A_ADDU(x)
+#define A_MIX_CVT_LSHR(x)  A_CVTU(x) A_LSHR(x)
+#define A_MIX_MIXH_FMA(x)  A_FMAMIX(x) A_FMA(x)
+#define A_MIX_MIXH_AND(x)  A_FMAMIX(x) A_AND(x)
+#define A_MIX_FMA_AND(x)   A_FMA(x) A_AND(x)
+#define A_MIX_FMA_FMAS(x)  A_FMA(x) A_FMAS(x)
+#define A_MIX_CVT_FMAS(x)  A_CVTU(x) A_FMAS(x)
 
 #define K1(NAME, OP) KERNEL(NAME, REP8(OP))
 K1(fma, A_FMA) K1(fma_s, A_FMAS) K1(fma_k, A_FMAK) K1(mul_k, A_MULK) K1(mul_lit, A_MULL) K1(add, A_ADD) K1(add_s, A_ADDS)
@@ -78,9 +91,11 @@ K1(and_or, A_ANDOR) K1(mad_u24, A_MADU24) K1(mul_u24, A_MULU24) K1(cvt_ubyte, A_
 K1(pk_min_u16, A_PKMINU) K1(pk_max_u16, A_PKMAXU) K1(fract, A_FRACT) K1(rndne, A_RNDNE) K1(cnd_vcc, A_CNDVCC) K1(sub_u32, A_SUBU)
 K1(cvt_f16, A_CVTH) K1(cvt_f32_f16, A_CVTFH) K1(dot2_f16, A_DOT2) K1(add_sdwa, A_SDWAADD) K1(cvt_sdwa_w1, A_CVTSDWA1)
 K1(cvt_u32, A_CVTU) K1(trunc, A_TRUNC) K1(med3, A_MED3) K1(cmp_sgpr, A_CMP) K1(cmp_vcc, A_CMPVCC) K1(mov, A_MOV)
-K1(readlane, A_RDLANE) K1(writelane, A_WRLANE)
+K1(readlane, A_RDLANE) K1(writelane, A_WRLANE) K1(mul_clamp, A_MULCLAMP) K1(fma_clamp, A_FMACLAMP) K1(mul_negabs, A_MULNEG)
 K1(mix_fma_cvt, A_MIX_FMA_CVT) K1(mix_2fma_cvt, A_MIX_2FMA_CVT) K1(mix_fma_cnd, A_MIX_FMA_CND) K1(mix_fma_med3, A_MIX_FMA_MED3)
 K1(mix_cvt_med3, A_MIX_CVT_MED3) K1(mix_fma_lshl, A_MIX_FMA_LSHL)
+K1(add_u32, A_ADDU) K1(mix_cvt_and, A_MIX_CVT_AND) K1(mix_cvt_lshl, A_MIX_CVT_LSHL) K1(mix_cvt_addu, A_MIX_CVT_ADDU) K1(mix_cvt_lshr, A_MIX_CVT_LSHR)
+K1(mix_fmamix_fma, A_MIX_MIXH_FMA) K1(mix_fmamix_and, A_MIX_MIXH_AND) K1(mix_fma_and, A_MIX_FMA_AND) K1(mix_fma_fmas, A_MIX_FMA_FMAS) K1(mix_cvt_fmas, A_MIX_CVT_FMAS)
 
 // packed fp32 needs register pairs
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -141,8 +156,10 @@ int main()
     RUN(fma_mix_lo,1) RUN(fma_mix_hi,1) RUN(pk_fma,2) RUN(and_b32,1) RUN(or_b32,1) RUN(lshl,1) RUN(lshr,1) RUN(bfe,1) RUN(lshl_add,1) RUN(add3,1)
     RUN(and_or,1) RUN(mad_u24,1) RUN(mul_u24,1) RUN(cvt_ubyte,1) RUN(perm,1) RUN(pk_min_u16,1) RUN(pk_max_u16,1) RUN(fract,1) RUN(rndne,1)
     RUN(cnd_vcc,1) RUN(sub_u32,1) RUN(cvt_f16,1) RUN(cvt_f32_f16,1) RUN(dot2_f16,1) RUN(add_sdwa,1) RUN(cvt_sdwa_w1,1) RUN(cvt_u32,1) RUN(trunc,1)
-    RUN(med3,1) RUN(cmp_sgpr,1) RUN(cmp_vcc,1) RUN(mov,1) RUN(readlane,1) RUN(writelane,1)
+    RUN(med3,1) RUN(cmp_sgpr,1) RUN(cmp_vcc,1) RUN(mov,1) RUN(readlane,1) RUN(writelane,1) RUN(mul_clamp,1) RUN(fma_clamp,1) RUN(mul_negabs,1)
     RUN(mix_fma_cvt,2) RUN(mix_2fma_cvt,3) RUN(mix_fma_cnd,2) RUN(mix_fma_med3,2) RUN(mix_cvt_med3,2) RUN(mix_fma_lshl,2)
+    RUN(add_u32,1) RUN(mix_cvt_and,2) RUN(mix_cvt_lshl,2) RUN(mix_cvt_addu,2) RUN(mix_cvt_lshr,2) RUN(mix_fmamix_fma,2) RUN(mix_fmamix_and,2)
+    RUN(mix_fma_and,2) RUN(mix_fma_fmas,2) RUN(mix_cvt_fmas,2)
 
     {   // fma_mix exactness
         const int n = 1 << 16;
