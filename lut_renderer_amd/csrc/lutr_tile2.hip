@@ -605,7 +605,7 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
     const float rcp_plane = 1.0f / (float)plane, rcp_nb = 1.0f / (float)nb;
     // Batches of kB nodes per lane: all kB global reads are issued before the first LDS write, so a restage costs about
     // one L2 round trip per batch instead of one per node (the wave is stalled meanwhile; 4 waves per SIMD cannot hide it).
-    constexpr int kB = LUTR_T2_KB_FAST > 0 && N::fast ? LUTR_T2_KB_FAST : 6;
+    constexpr int kB = 6;          // (9 and 18 for the 8-byte nodes of the fast windows were measured: no difference)
     for (int base = 0; base < total; base += 64 * kB) {
         int dst[kB];
         typename std::conditional<N::fast, uint2, float4>::type val[kB];
@@ -799,10 +799,12 @@ DEV Rgb3 px_blend(const LutConsts &L, const PxC &c, const Taps<INTERP, V> &T)
 
 // (int)(v * M) clipped to [0, M]; V >= V_UNIT: every lattice node lies in [0, 1], the truncation alone lands in [0, M]
 // (all weights and nodes >= 0, rounding of products and sums is monotone): the clip is dead code.
-template <int V>
+template <int INTERP, int V>
 DEV Rgb3 px_quant(const LutConsts &L, const Rgb3 &v)
 {
     Rgb3 o;
+    // (Measured for the fast tetrahedral kernel: rounding by two full-rate adds of 1.5 * 2^23 on a chain started at -0.5 + 2^-12
+    // instead of the quarter-rate v_trunc_f32 -- three more instructions per pixel, 3 % slower: instruction issue binds first.)
     if constexpr (V >= V_UNIT) { o.r = truncf(v.r); o.g = truncf(v.g); o.b = truncf(v.b); }
     else { o.r = med3(truncf(v.r), 0.0f, L.maxf); o.g = med3(truncf(v.g), 0.0f, L.maxf); o.b = med3(truncf(v.b), 0.0f, L.maxf); }
     return o;
@@ -862,9 +864,6 @@ DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, co
 #endif
 #ifndef LUTR_T2_PIPE_FAST
 #define LUTR_T2_PIPE_FAST 0
-#endif
-#ifndef LUTR_T2_KB_FAST
-#define LUTR_T2_KB_FAST 0         // nodes per lane and batch when a fast (8-byte node) window is staged; 0 = as the strict kernels (6)
 #endif
 #ifndef LUTR_T2_TB_FAST
 #define LUTR_T2_TB_FAST 4
@@ -930,7 +929,7 @@ DEV void tile_body(const LutConsts &L, const YuvConsts &K_, const Win &W_, const
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-            for (int t = 0; t < TB; t++) o[qb + t] = px_quant<V>(L, px_blend<INTERP, V>(L, pc[t], tp[t]));
+            for (int t = 0; t < TB; t++) o[qb + t] = px_quant<INTERP, V>(L, px_blend<INTERP, V>(L, pc[t], tp[t]));
         }
         float rs[NCG], gs[NCG], bs[NCG];
 #pragma unroll
