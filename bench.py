@@ -408,8 +408,8 @@ def main():
                 st = eng.tile_stats(False)
                 key = dname if len(modes) == 1 else f"{dname}/{mode}"
                 extra[key] = {"Mpx_s": round(nf_x * w * h / k2 / 1e6, 1), "kernel": eng.last_kernel,
-                              "tiles": st["tiles"], "window_misses": st["misses"], "gather_tiles": st["global_tiles"],
-                              "windows_staged": st["staged"]}
+                              "tiles": st["tiles"], "tube_tiles": st["tube_tiles"], "level2_tiles": st["level2_tiles"],
+                              "window_misses": st["misses"], "gather_tiles": st["global_tiles"], "windows_staged": st["staged"]}
                 log(f"[extra] {key:22s} {extra[key]}")
             del s2
 

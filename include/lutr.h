@@ -231,9 +231,9 @@ int lutr_ctx_set_variant(lutr_ctx *ctx, int variant);
 /* name of the kernel variant the last apply call launched ("" before the first) */
 const char *lutr_ctx_last_kernel(lutr_ctx *ctx);
 /* Statistics of the LDS-window tile kernels, accumulated since the previous call.  out[8] (may be
- * NULL) = { tiles, full passes that missed the window, tiles done by the global-gather body, windows
- * staged, shader clock in MHz, longest wave lifetime in us, summed wave lifetimes in us, tiles that needed the exact
- * (second-level) window test }.  The round-2 kernels report no clock / lifetime figures (0).
+ * NULL) = { tiles, restage attempts (tiles neither the tube nor the wave's window could take), tiles done by the
+ * global-gather body, windows staged, 0, 0, tiles served by the workgroup-shared grey tube (no window needed),
+ * tiles that needed the exact (second-level) window test }.
  * Then collection is enabled (and zeroed) or disabled. */
 int lutr_ctx_tile_stats(lutr_ctx *ctx, int enable, uint64_t out[8]);
 /* the constant block the YUV kernels use, for cross-checking against the oracle: 32 floats */

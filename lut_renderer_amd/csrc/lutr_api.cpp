@@ -325,9 +325,8 @@ int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[8])
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
             for (int i = 0; i < 4; i++) out[i] = h[i];
-            out[4] = h[5] ? (uint64_t)(100.0 * h[4] / h[5] + 0.5) : 0;          // shader clock, MHz (memtime / 100 MHz realtime)
-            out[5] = h[10] / 100;                                                 // longest wave lifetime, us
-            out[6] = (uint64_t)h[11] * 64 / 100;                   // summed wave lifetimes, us
+            out[4] = out[5] = 0;                                    // (round 1 reported a clock and wave lifetimes here)
+            out[6] = h[12];                                         // tiles served by the workgroup's grey tube
             out[7] = h[6];                                          // tiles that needed the second-level (exact) window test
             if (getenv("LUTR_DEBUG"))
             {

@@ -145,6 +145,10 @@ struct Geom {
     int max_raw;          // 2^din - 1: a raw code above it cannot be trusted to stay inside the table
     int whole;            // 1: the WHOLE lattice fits the workgroup's LDS (N <= 21 strict / 25 fast at 10 bit): staged once
                           // per workgroup, shared by its waves, no windows, no validity tests -- content cannot matter
+    int tube_h;           // > 0: a workgroup-shared "grey tube" of the lattice is staged once, behind the scratch area: every cell with
+                          // |pg - pr| <= tube_h and |pb - pr| <= tube_h, all of r.  Tiles whose chroma keeps them inside it (tube_holds)
+                          // need no window at all; the per-wave windows serve the saturated rest.
+    float tube_t;         // the test: |gv - rv| and |bu - rv| (RGB codes, chroma only) must stay <= tube_t over the lane's unit
     unsigned *queue;      // device counter, set by the launcher before every launch
     unsigned *stats;      // optional device counters; nullptr = off
 };
@@ -472,6 +476,33 @@ DEV bool cells_hold(int scratch_off, const Bnd &b)
     const float2 hi = *(const float2 *)(smem + scratch_off + 16);   // g_hi, b_hi
     const bool ok = b.rmin >= lo.x && b.rmax <= lo.w && b.gmin >= lo.y && b.gmax <= hi.x && b.bmin >= lo.z && b.bmax <= hi.y;
     return __all(ok);
+}
+
+template <int WIN> DEV int lo_of_(uint32_t mn) { const int a = (int)(mn & 0xffffu), b = (int)(mn >> 16); const int v = a < b ? a : b; return WIN ? v : v >> 8; }
+template <int WIN> DEV int hi_of_(uint32_t mx) { const int a = (int)(mx & 0xffffu), b = (int)(mx >> 16); const int v = a > b ? a : b; return WIN ? v : v >> 8; }
+
+// ---------------------------------------------------------------- the grey tube
+// Is every pixel of the tile inside the tube?  In sheared coordinates luma cancels out of the two difference axes (map_box), so the
+// answer depends on chroma alone: with dG = gv - rv and dB = bu - rv (monotone in cb and cr, evaluated at the corners of the lane's
+// chroma extremes), every cell has |pg - pr| <= H and |pb - pr| <= H as soon as |dG|, |dB| <= tube_t =
+// (H + 1 - slack) / kappa - 1 - eps -- map_box's own bound solved for d.  Where FFmpeg's clip to [0, M] binds, the clipped
+// difference lies between 0 and the unclipped one, and 0 is inside.  One vote per tile, ~35 VALU per lane, no luma needed.
+template <int WIN, int PRE>
+DEV bool tube_holds(const YuvConsts &K, const Geom &TG, const Ext &e)
+{
+    float cb0 = (float)lo_of_<WIN>(e.cbmin), cb1 = (float)hi_of_<WIN>(e.cbmax);
+    float cr0 = (float)lo_of_<WIN>(e.crmin), cr1 = (float)hi_of_<WIN>(e.crmax);
+    if constexpr (PRE) {       // the range/depth prologue is a monotone map of each plane
+        cb0 = qclip(fma_(K.pc, cb0, K.pcb), K.pre_max); cb1 = qclip(fma_(K.pc, cb1, K.pcb), K.pre_max);
+        cr0 = qclip(fma_(K.pc, cr0, K.pcb), K.pre_max); cr1 = qclip(fma_(K.pc, cr1, K.pcb), K.pre_max);
+    }
+    const float cbd0 = cb0 - K.coff, cbd1 = cb1 - K.coff, crd0 = cr0 - K.coff, crd1 = cr1 - K.coff;
+    // krv, kbu > 0; kgu, kgv < 0 for every matrix (make_yuv_consts)
+    const float rv0 = K.krv * crd0, rv1 = K.krv * crd1, bu0 = K.kbu * cbd0, bu1 = K.kbu * cbd1;
+    const float gv0 = fma_(K.kgu, cbd1, K.kgv * crd1), gv1 = fma_(K.kgu, cbd0, K.kgv * crd0);      // min, max
+    const float dg0 = gv0 - rv1, dg1 = gv1 - rv0, db0 = bu0 - rv1, db1 = bu1 - rv0;
+    const float worst = vmax3(fmaxf(-dg0, dg1), -db0, db1);
+    return __all(worst <= TG.tube_t);
 }
 
 // ---------------------------------------------------------------- restage
@@ -937,7 +968,7 @@ DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, co
 }
 
 #ifndef LUTR_T2_PIPE
-#define LUTR_T2_PIPE 1            // software pipeline across pixel groups: group g+1's coordinate reads are issued before group g's blend
+#define LUTR_T2_PIPE 0            // 1: software pipeline across pixel groups (group g+1's coordinate reads before group g's blend): +4 % for the strict kernels while they had registers for it; with the tube state live it spills (-2.7 %)
 #endif
 #ifndef LUTR_T2_FENCE_ALL
 #define LUTR_T2_FENCE_ALL 0
@@ -1134,11 +1165,36 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         }
         __syncthreads();
     }
+    const int tube_nb = 2 * TG.tube_h + 3;                    // nodes across each difference axis: cells -H..H, corners -H-1..H+1
+    const int tube_nodes = TG.tube_h > 0 ? L.n1 * tube_nb * tube_nb : 0;
+    if (TG.tube_h > 0) {
+        // node (ir, ig, ib) = lattice (r, r + ig - H - 1, r + ib - H - 1), clamped (a clamped node is never read by a valid pixel)
+        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
+        const int plane = tube_nb * tube_nb, nmax = L.n1 - 1;
+        for (int i = threadIdx.x; i < tube_nodes; i += 64 * LUTR_T2_WPB) {
+            const int ir = i / plane, rem = i - ir * plane, ig = rem / tube_nb, ib = rem - ig * tube_nb;
+            const int g = min(max(ir + ig - TG.tube_h - 1, 0), nmax), b = min(max(ir + ib - TG.tube_h - 1, 0), nmax);
+            const int src = (ir * L.n1 + g) * L.n1 + b;
+            if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[src];
+            else {
+                const float4 v = L.lat[src];
+                if constexpr (N::lds == 16) ((float4 *)dst)[i] = v;
+                else { float *q = (float *)(dst + 12 * i); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
+            }
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int tab_bytes = TG.tab_entries * 8;
     const int scratch_off = tab_bytes + wib * 64;             // the window's cell ranges (second-level test)
-    const int slice_off = tab_bytes + LUTR_T2_WPB * 64 + wib * TG.win_nodes * N::lds;
+    const int tube_off = tab_bytes + LUTR_T2_WPB * 64;
+    const int slice_off = tube_off + tube_nodes * N::lds + wib * TG.win_nodes * N::lds;
+    Win Wt;                                                   // the tube as a window: same address form as a staged one
+    Wt.o_g = N::lds * tube_nb; Wt.o_r = N::lds * (tube_nb * tube_nb - tube_nb - 1);
+    Wt.fr = (float)Wt.o_r; Wt.fg = (float)Wt.o_g; Wt.fb = (float)N::lds;
+    Wt.fc = (float)(lds_base() + tube_off + N::lds * ((TG.tube_h + 1) * tube_nb + TG.tube_h + 1));
+    unsigned st_tube = 0;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     bool first = true;
     if (!claim_chunk(TG, lane, fr, sx, ry, rem, first)) return;
@@ -1238,7 +1294,14 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         TK(tk_wait)                  // ... and this is the wait for this tile's own loads
 #endif
         const Ext e = extremes<WIN, WOUT, CSX, CSY>(in);
-        bool use_lds = box_holds(scratch_off, e);             // first level: raw extremes against the window's raw box
+        bool use_tube = false;
+        if (TG.tube_h > 0) {
+            // level 0: the tile's chroma keeps it inside the workgroup's grey tube (and its raw codes are legal for the clamp-free body)
+            const uint32_t top = pack_hi<WIN>(TG.max_raw);
+            const bool legal = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
+            use_tube = legal && tube_holds<WIN, PRE>(K, TG, e);
+        }
+        bool use_lds = use_tube || box_holds(scratch_off, e);  // first level: raw extremes against the window's raw box
         if (LUTR_T2_EXP >= 1 && have_win) use_lds = true;
         TK(tk_head)
         st_tiles++;
@@ -1246,6 +1309,8 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             // every cell is in LDS; only raw codes above 2^din - 1 (which the padded table does not cover) need the clamping body
             const uint32_t top = pack_hi<WIN>(TG.max_raw);
             use_lds = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
+        } else if (use_tube) {
+            st_tube++;
         } else if (use_lds) {
 #ifdef LUTR_T2_DEBUG_STATS
             if (l2run > 0 && lane == 0) atomicAdd(&TG.stats[21 + (l2run <= 1 ? 0 : l2run <= 2 ? 1 : l2run <= 4 ? 2 : l2run <= 8 ? 3 : l2run <= 16 ? 4 : 5)], (unsigned)l2run);
@@ -1310,7 +1375,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             for (int k = 0; k < T::CWO; k++) { out.cb[k] = in.cb[k % T::CWI]; out.cr[k] = in.cr[k % T::CWI]; }
         } else
         if (use_lds) {
-            tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out); TK(tk_body)
+            tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, use_tube ? Wt : W, TG, in, out); TK(tk_body)
             if constexpr (LUTR_T2_EXP >= 5) {      // the body again, EXP - 4 times, on inputs the compiler cannot tell are the same
 #pragma unroll 1
                 for (int rep = 0; rep < LUTR_T2_EXP - 4; rep++) {
@@ -1343,6 +1408,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     if (TG.stats && lane == 0) {
         atomicAdd(&TG.stats[0], st_tiles); atomicAdd(&TG.stats[1], cnt[1]);
         atomicAdd(&TG.stats[2], cnt[8]); atomicAdd(&TG.stats[3], cnt[9]); atomicAdd(&TG.stats[6], cnt[0]);
+        atomicAdd(&TG.stats[12], st_tube);
     }
 }
 
@@ -1456,12 +1522,34 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     tg.max_raw = (1 << din) - 1;
     const int node = vv == V_FAST ? 8 : (mode == LUTR_INTERP_TRILINEAR ? 16 : 12);
     const int blocks_per_cu = waves_per_cu / LUTR_T2_WPB > 0 ? waves_per_cu / LUTR_T2_WPB : 1;
-    int cap = (163840 / blocks_per_cu - tg.tab_entries * 8 - 64 * LUTR_T2_WPB) / (node * LUTR_T2_WPB);
-    if (const char *e = getenv("LUTR_WIN_NODES")) { const int c = atoi(e); if (c >= 64 && c < cap) cap = c; }
+    const int lds_block = 163840 / blocks_per_cu - tg.tab_entries * 8 - 64 * LUTR_T2_WPB;
     // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
-    tg.whole = (blocks_per_cu == 1 && !getenv("LUTR_NO_WHOLE") &&
-                tg.tab_entries * 8 + 64 * LUTR_T2_WPB + whole_bytes <= 163840) ? 1 : 0;
+    tg.whole = (blocks_per_cu == 1 && !getenv("LUTR_NO_WHOLE") && whole_bytes <= lds_block) ? 1 : 0;
+    // The grey tube (Geom::tube_h): all of r, |g - r| and |b - r| up to H cells.  Needs the table variants (equal channel scales: the
+    // chroma-only bound of map_box), a blend (nearest rounds to a node, the bound is for floor), and enough room left for windows.
+    // H: 5 cells of a 33^3 lattice = 40 8-bit codes of G-R or B-R, which holds 81 % of the tiles of the natural test frames and 60 % at
+    // sigma = 8 codes of chroma noise; 34 x 13 x 13 nodes = 46 KB as fp16.  Scaled with the lattice; too thin to pay above ~40^3.
+    tg.tube_h = 0; tg.tube_t = 0.0f;
+    long long tube_bytes = 0;
+    if (!tg.whole && vv >= V_TAB && mode != LUTR_INTERP_NEAREST) {
+        int h = (5 * (L.n1 - 2) + 16) / 32;                       // 5 at 33^3
+        if (const char *e = getenv("LUTR_TUBE_H")) h = atoi(e);
+        const float kappa = L.sc[0] * L.scale_f;
+        const float eps = K.max_l * (1.0f / 2097152.0f) + 1e-3f;                 // as map_box
+        const float slack = 1.0f + 2.0f * L.lut_max * (1.0f / 2097152.0f) + 2e-3f;
+        while (h >= 3) {
+            const long long nb = 2 * h + 3, bytes = (long long)L.n1 * nb * nb * node;
+            const float t = ((float)(h + 1) - slack) / kappa - 1.0f - eps;
+            if (bytes <= lds_block * 2 / 5 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= 384 && t > 0.0f) {
+                tg.tube_h = h; tg.tube_t = t; tube_bytes = bytes;
+                break;
+            }
+            h--;
+        }
+    }
+    int cap = (int)((lds_block - tube_bytes) / (node * LUTR_T2_WPB));
+    if (const char *e = getenv("LUTR_WIN_NODES")) { const int c = atoi(e); if (c >= 64 && c < cap) cap = c; }
     if (!tg.whole && cap < 128) return nullptr;
     tg.win_nodes = tg.whole ? 0 : cap;
     tg.queue = queue; tg.stats = stats;
@@ -1469,7 +1557,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     const dim3 grid((waves + LUTR_T2_WPB - 1) / LUTR_T2_WPB), block(64 * LUTR_T2_WPB);
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_T2_WPB), 1, st) != hipSuccess) return nullptr;
     const size_t lds = (size_t)tg.tab_entries * 8 + 64 * LUTR_T2_WPB +
-                       (tg.whole ? (size_t)whole_bytes : (size_t)LUTR_T2_WPB * tg.win_nodes * node);
+                       (tg.whole ? (size_t)whole_bytes : (size_t)tube_bytes + (size_t)LUTR_T2_WPB * tg.win_nodes * node);
     Planes2 TP;
     for (int i = 0; i < 3; i++) {
         TP.s[i] = P.s[i]; TP.d[i] = P.d[i];
@@ -1477,15 +1565,15 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         TP.sfs[i] = (unsigned long long)P.sfs[i]; TP.dfs[i] = (unsigned long long)P.dfs[i];
     }
     if (getenv("LUTR_DEBUG"))
-        fprintf(stderr, "[lutr t2] nsx %d nry %d chunk %d chunks %d blocks %u lds/block %zu win_nodes %d tab %d variant %d\n",
-                tg.nsx, tg.nry, tg.ch, tg.nchunks, grid.x, lds, tg.win_nodes, tg.tab_entries, vv);
+        fprintf(stderr, "[lutr t2] nsx %d nry %d chunk %d chunks %d blocks %u lds/block %zu win_nodes %d tab %d variant %d tube h %d t %.1f\n",
+                tg.nsx, tg.nry, tg.ch, tg.nchunks, grid.x, lds, tg.win_nodes, tg.tab_entries, vv, tg.tube_h, tg.tube_t);
 
 #define T2_LAUNCH(WI, WO, X, Y, I, PR, VV, NAME) \
     do { \
         auto kern = k_yuv_tile2<WI, WO, X, Y, I, PR, VV>; \
         allow_lds((const void *)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, st, L, K, TP, G, tg); \
-        return tg.whole ? NAME "+whole-lattice" : NAME; \
+        return tg.whole ? NAME "+whole-lattice" : (tg.tube_h ? NAME "+tube" : NAME); \
     } while (0)
 #define T2_NAME(WI, WO, X, Y, I, SUF) "k_yuv_tile2<" #WI #WO "," #X #Y "," #I SUF ">"
 #define T2_CASE(WI, WO, X, Y, I) \

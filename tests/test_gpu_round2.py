@@ -418,3 +418,41 @@ def test_three_process_stage_streams_frames_through_the_engine(orc, cube_dir, tm
     finally:
         os.chdir(cwd)
     assert "decoder exited" in log2.getvalue()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["strict", "fast"])
+def test_grey_tube_serves_low_saturation_tiles_and_saturated_ones_fall_through(engine, orc, cube_dir, precision):
+    """The workgroup-shared grey tube (csrc/lutr_tile2.hip tube_holds): near-neutral content of ANY luma is served without a
+    window -- luma noise that would break every raw box does not matter --, saturated content goes through the per-wave
+    windows as before, and both are bit-exact.  Frames: (a) grey ramp with heavy luma noise and +-6 codes of chroma,
+    (b) the same luma with chroma pushed to +-300 codes (10 bit) in four flat quadrants."""
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    engine.set_lut(lut)
+    engine.set_variant("vec_lds")
+    engine.set_precision(precision)
+    rng = np.random.default_rng(77)
+    w, h = 1024, 256
+    y = np.clip(np.linspace(64, 940, w)[None, :] + rng.normal(0, 60, size=(h, w)), 64, 940).astype(np.uint16)
+    grey = [y, (512 + rng.integers(-6, 7, size=(h // 2, w // 2))).astype(np.uint16),
+            (512 + rng.integers(-6, 7, size=(h // 2, w // 2))).astype(np.uint16)]
+    cb = np.full((h // 2, w // 2), 512, np.int32); cr = cb.copy()
+    cb[:, : w // 4] += 300; cb[:, w // 4:] -= 300
+    cr[: h // 4, :] += 300; cr[h // 4:, :] -= 300
+    sat = [y, cb.astype(np.uint16), cr.astype(np.uint16)]
+    k = orc.yuv_constants(din=10)
+    try:
+        for name, src, expect_tube in (("grey", grey, True), ("saturated", sat, False)):
+            engine.tile_stats(True)
+            got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le")
+            st = engine.tile_stats(False)
+            assert "tube" in engine.last_kernel, engine.last_kernel
+            if expect_tube:
+                assert st["tube_tiles"] == st["tiles"] and st["misses"] == 0 and st["global_tiles"] == 0, st
+            else:
+                assert st["tube_tiles"] == 0, st
+            want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src, fast=precision == "fast")
+            _assert_equal(_to_np(got, np.uint16), want, f"tube {precision} {name}")
+    finally:
+        engine.set_precision("strict")
+        engine.set_variant("auto")
