@@ -1503,9 +1503,12 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     // lanes across x: 16 (x 4 down: 128 x 8 px at 10-bit 4:2:0) unless another shape wastes 2 % fewer lanes at the frame's edges.
     // Compact tiles see fewer colours: with the tube, 16 x 4 measures 625 / 564 Gpx/s fast / strict against 607 / 542 for 32 x 2
     // and 615 / 562 for 8 x 8 (UHD).
-    int best = 4;
+    // 4:2:2 / 4:4:4 (one row per unit) are on the memory side and want 512-byte runs per tile row: 32 x 2 lanes there
+    // (yuv422p10le 489 vs 341 Gpx/s, yuv444p10le 407 vs 332).
+    int best = csy ? 4 : 5;
     double best_eff = -1.0;
-    for (int l : {4, 5, 3, 6, 2}) {
+    const int order[2][5] = {{5, 4, 6, 3, 2}, {4, 5, 3, 6, 2}};
+    for (int l : order[csy ? 1 : 0]) {
         const int lw = 1 << l, lh = 64 >> l;
         const double eff = ((double)uw / (((uw + lw - 1) / lw) * lw)) * ((double)urows / (((urows + lh - 1) / lh) * lh));
         if (eff > best_eff + 0.02) { best_eff = eff; best = l; }
