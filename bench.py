@@ -41,7 +41,7 @@ sys.path.insert(0, str(ROOT))
 
 SIZES = {"1080p": (1920, 1080), "uhd": (3840, 2160), "8k": (7680, 4320)}
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-EXTRA_DISTS = ("noise8", "noise16", "noise64", "uniform")
+EXTRA_DISTS = ("vivid", "noise8", "noise16", "noise64", "uniform")
 
 
 def log(*a):

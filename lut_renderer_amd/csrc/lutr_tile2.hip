@@ -1534,13 +1534,17 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
     tg.whole = (blocks_per_cu == 1 && !getenv("LUTR_NO_WHOLE") && whole_bytes <= lds_block) ? 1 : 0;
     // The grey tube (Geom::tube_h): all of r, |g - r| and |b - r| up to H cells.  Needs the table variants (equal channel scales: the
-    // chroma-only bound of map_box), a blend (nearest rounds to a node, the bound is for floor), and enough room left for windows.
-    // H: 5 cells of a 33^3 lattice = 40 8-bit codes of G-R or B-R, which holds 81 % of the tiles of the natural test frames and 60 % at
-    // sigma = 8 codes of chroma noise; 34 x 13 x 13 nodes = 46 KB as fp16.  Scaled with the lattice; too thin to pay above ~40^3.
+    // chroma-only bound of map_box), a blend (nearest rounds to a node, the bound is for floor), and room left for windows.
+    // H: as wide as 70 % of the block's LDS allows while every wave keeps a window of 256 nodes, at most 8 cells of a 33^3 lattice
+    // (+-64 8-bit codes of G-R and B-R; 34 x 19 x 19 fp16 nodes = 98 KB, windows of 367 nodes).  Measured, UHD yuv420p10le fast,
+    // H = 5 / 7 / 8 / 9: natural frames 611 / 620 / 628 / 636 Gpx/s, three times the chroma 516 / 521 / 530 / 519, sigma = 8 noise
+    // 503 / 543 / 550 / 569, sigma = 16 250 / 388 / 481 / 500: the tube, not the windows, is what carries natural content; 9 leaves
+    // windows of 197 nodes and starts to cost saturated frames.  The strict kernels (12-byte nodes) get H = 6.
     tg.tube_h = 0; tg.tube_t = 0.0f;
     long long tube_bytes = 0;
-    if (!tg.whole && vv >= V_TAB && mode != LUTR_INTERP_NEAREST) {
-        int h = (5 * (L.n1 - 2) + 16) / 32;                       // 5 at 33^3
+    // (65^3: a tube that fits is 5 of ITS cells wide, +-20 8-bit codes -- 497 / 427 Gpx/s with it, 530 / 492 without: off above 40^3)
+    if (!tg.whole && vv >= V_TAB && mode != LUTR_INTERP_NEAREST && (L.n1 <= 41 || getenv("LUTR_TUBE_H"))) {
+        int h = (8 * (L.n1 - 2) + 16) / 32;                       // 8 at 33^3
         if (const char *e = getenv("LUTR_TUBE_H")) h = atoi(e);
         const float kappa = L.sc[0] * L.scale_f;
         const float eps = K.max_l * (1.0f / 2097152.0f) + 1e-3f;                 // as map_box
@@ -1548,7 +1552,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         while (h >= 3) {
             const long long nb = 2 * h + 3, bytes = (long long)L.n1 * nb * nb * node;
             const float t = ((float)(h + 1) - slack) / kappa - 1.0f - eps;
-            if (bytes <= lds_block * 2 / 5 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= 384 && t > 0.0f) {
+            if (bytes <= (long long)lds_block * 7 / 10 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= 256 && t > 0.0f) {
                 tg.tube_h = h; tg.tube_t = t; tube_bytes = bytes;
                 break;
             }

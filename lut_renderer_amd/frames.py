@@ -53,7 +53,7 @@ def _bilinear_field(rng, h: int, w: int, lo: float, hi: float) -> np.ndarray:
 
 
 def natural_yuv(w: int, h: int, depth: int = 10, csx: int = 1, csy: int = 1, k: int = 0,
-                full_range: bool = False, noise_sigma_10bit: float = 2.0) -> List[np.ndarray]:
+                full_range: bool = False, noise_sigma_10bit: float = 2.0, chroma_gain: float = 1.0) -> List[np.ndarray]:
     rng = np.random.default_rng(SEED_BASE + k)
     (ylo, yhi), (clo, chi) = _ranges(depth, full_range)
     ch, cw = chroma_shape(w, h, csx, csy)
@@ -76,6 +76,8 @@ def natural_yuv(w: int, h: int, depth: int = 10, csx: int = 1, csy: int = 1, k: 
                                        np.abs(cyy * (1 << csy) - py) / ry)) / edge, 0.0, 1.0)
         cb += dcb * mc
         cr += dcr * mc
+    cb *= chroma_gain
+    cr *= chroma_gain
     sig = noise_sigma_10bit * s
     yc = ylo + np.clip(y, 0.0, 1.0) * (yhi - ylo) + rng.normal(0.0, sig, size=(h, w))
     cbc = mid + cb * (chi - clo) + rng.normal(0.0, sig, size=(ch, cw))
@@ -129,6 +131,8 @@ def make_yuv(dist: str, w: int, h: int, depth: int, csx: int, csy: int, k: int =
         return uniform_yuv(w, h, depth, csx, csy, k, full_range)
     if dist == "natural":
         return natural_yuv(w, h, depth, csx, csy, k, full_range)
+    if dist == "vivid":        # the natural frame with three times the chroma: saturated fields and patches, far from the grey axis
+        return natural_yuv(w, h, depth, csx, csy, k, full_range, chroma_gain=3.0)
     if dist.startswith("noise"):
         return natural_yuv(w, h, depth, csx, csy, k, full_range, noise_sigma_10bit=_noise_sigma(dist))
     raise ValueError(f"unknown distribution '{dist}'")

@@ -282,7 +282,7 @@ def test_bench_single_gpu_line_has_every_contract_field():
         assert key in d, key
     assert d["config"]["range_src"] == "pc" and "pre" in d["config"]["kernel"]
     assert "pre" in d["host_pipeline"]["kernel"] and d["host_pipeline"]["prologue"].startswith("scale=in_range=pc")
-    assert set(d["extra_Mpx_s"]) == {"noise8", "noise16", "noise64", "uniform"}
+    assert set(d["extra_Mpx_s"]) == {"vivid", "noise8", "noise16", "noise64", "uniform"}
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
 

@@ -109,6 +109,9 @@ def test_noise_sweep_distributions():
     c = frames.make_yuv("noise64", 128, 64, 10, 1, 1, k=0)
     assert np.abs(c[0].astype(int) - b[0].astype(int)).std() > 20
     assert c[1].min() >= 64 and c[1].max() <= 960 and c[0].max() <= 940
+    v = frames.make_yuv("vivid", 128, 64, 10, 1, 1, k=0)                  # the natural frame with three times the chroma
+    assert np.array_equal(v[0], b[0])
+    assert np.abs(v[1].astype(int) - 512).mean() > 2.0 * np.abs(b[1].astype(int) - 512).mean()
     g = frames.make_rgb("noise16", 64, 32, 8, k=1)
     assert g[0].dtype == np.uint8 and g[0].shape == (32, 64)
     for bad in ("noise", "noisex", "noise-4", "plasma"):
