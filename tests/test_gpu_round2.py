@@ -456,3 +456,32 @@ def test_grey_tube_serves_low_saturation_tiles_and_saturated_ones_fall_through(e
     finally:
         engine.set_precision("strict")
         engine.set_variant("auto")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["strict", "fast"])
+@pytest.mark.parametrize("n", [22, 27, 40, 41])
+def test_tube_and_windows_across_lattice_sizes(engine, orc, n, precision):
+    """Lattice sizes around the modes' limits (whole-lattice up to 21 / 25, tube up to 40, windows only above), three kinds of
+    content, two interpolations, 10- and 8-bit 4:2:0: every combination bit-exact against the oracle (the tube's width and its
+    chroma bound scale with the lattice)."""
+    lat = cube.log709_lattice(n)
+    one = np.ones(3, np.float32)
+    engine.set_lut(cube.CubeLut(n, one, lat))
+    engine.set_variant("vec_lds")
+    engine.set_precision(precision)
+    try:
+        for fmt, depth in (("yuv420p10le", 10), ("yuv420p", 8)):
+            k = orc.yuv_constants(din=depth, dl=depth, dout=depth)
+            dt = np.uint16 if depth > 8 else np.uint8
+            for dist in ("natural", "vivid", "uniform"):
+                src = frames.make_yuv(dist, 512, 96, depth, 1, 1, k=n)
+                for mode in ("tetrahedral", "trilinear"):
+                    got = engine.apply_yuv(_to_dev(src, engine), pix_fmt=fmt, interp=mode)
+                    name = engine.last_kernel
+                    assert ("tube" in name) == (n <= 40 and "whole" not in name), (name, n)
+                    want = orc.apply_yuv(lat, one, mode, k, depth, depth, depth, 1, 1, src, fast="fast" in name)
+                    _assert_equal(_to_np(got, dt), want, f"n={n} {precision} {fmt} {dist} {mode} {name}")
+    finally:
+        engine.set_precision("strict")
+        engine.set_variant("auto")
