@@ -149,9 +149,15 @@ const char *lutr_last_error(void);
 int  lutr_cube_parse(const char *path, float **rgb, int *n, float scale[3]);
 void lutr_cube_free(float *rgb);
 /* Any 3D LUT file lut3d's file= option accepts, chosen by extension like FFmpeg does: .cube (as above),
- * .dat, .3dl, .m3d, .csp (cineSpace without a pre-LUT shaper; a file with one is LUTR_EINVAL).  Same
- * outputs as lutr_cube_parse; free with lutr_cube_free.  Unknown extension: LUTR_EINVAL. */
+ * .dat, .3dl, .m3d, .csp (cineSpace).  Same outputs as lutr_cube_parse; free with lutr_cube_free.  Unknown extension: LUTR_EINVAL.
+ * A .csp file whose three channels carry a pre-LUT (a 1D shaper ahead of the cube, lut3d's `prelut`) needs lutr_lut_parse_ex:
+ * lutr_lut_parse returns LUTR_EINVAL for it rather than dropping the shaper. */
 int  lutr_lut_parse(const char *path, float **rgb, int *n, float scale[3]);
+/* As lutr_lut_parse, plus the file's prelut as lut3d builds it (/root/reference never sees it: FFmpeg's vf_lut3d.c parse_cinespace):
+ * *prelut = 3 x *prelut_size floats (channel c at [c * size]; size is 65536) sampled at prelut_min[c] + i / prelut_scale[c],
+ * or NULL / 0 when the file has none.  Free *prelut with lutr_cube_free.  Pass it to lutr_ctx_set_prelut after lutr_ctx_set_lut. */
+int  lutr_lut_parse_ex(const char *path, float **rgb, int *n, float scale[3], float **prelut, int *prelut_size,
+                       float prelut_min[3], float prelut_scale[3]);
 
 /* ---- context ---- */
 int  lutr_ctx_create(int device, lutr_ctx **out);
@@ -164,8 +170,12 @@ void lutr_ctx_destroy(lutr_ctx *ctx);
 int  lutr_ctx_set_stream(lutr_ctx *ctx, void *hip_stream);
 int  lutr_ctx_sync(lutr_ctx *ctx);
 
-/* upload a host lattice (layout of lutr_cube_parse) */
+/* upload a host lattice (layout of lutr_cube_parse); drops a prelut set earlier */
 int  lutr_ctx_set_lut(lutr_ctx *ctx, const float *rgb, int n, const float scale[3]);
+/* lut3d's prelut for the lattice just set (layout of lutr_lut_parse_ex; size 0 or prelut NULL removes it).  Every sample then goes
+ * through FFmpeg's apply_prelut (linear interpolation in the 1D table) before the cube.  With a prelut the calls run on the
+ * generic / vector kernels (the LDS tile kernels and the fast precision do not take one). */
+int  lutr_ctx_set_prelut(lutr_ctx *ctx, const float *prelut, int size, const float prelut_min[3], const float prelut_scale[3]);
 /* multi-GPU: a non-root rank allocates the device lattice without filling it, the host
  * broadcasts into the pointer returned by lutr_ctx_lut_device (RCCL, root = the rank that
  * called lutr_ctx_set_lut), then every rank may apply. */

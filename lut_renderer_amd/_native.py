@@ -25,7 +25,7 @@ PRECISION = {"strict": 0, "fast": 1}
 #: every symbol include/lutr.h declares (tests check the library exports each one)
 SYMBOLS = (
     "lutr_version", "lutr_last_error",
-    "lutr_cube_parse", "lutr_cube_free", "lutr_lut_parse",
+    "lutr_cube_parse", "lutr_cube_free", "lutr_lut_parse", "lutr_lut_parse_ex", "lutr_ctx_set_prelut",
     "lutr_ctx_create", "lutr_ctx_destroy", "lutr_ctx_set_stream", "lutr_ctx_sync",
     "lutr_ctx_set_lut", "lutr_ctx_lut_alloc", "lutr_ctx_lut_device", "lutr_ctx_lut_seal",
     "lutr_lattice_bytes", "lutr_lut_broadcast",
@@ -96,6 +96,9 @@ def load() -> C.CDLL:
     lib.lutr_last_error.restype = cp
     lib.lutr_cube_parse.argtypes = [cp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(ci), C.POINTER(C.c_float)]
     lib.lutr_lut_parse.argtypes = lib.lutr_cube_parse.argtypes
+    lib.lutr_lut_parse_ex.argtypes = list(lib.lutr_cube_parse.argtypes) + [C.POINTER(C.POINTER(C.c_float)), C.POINTER(ci),
+                                                                           C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.lutr_ctx_set_prelut.argtypes = [vp, C.POINTER(C.c_float), ci, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.lutr_cube_free.argtypes = [C.POINTER(C.c_float)]
     lib.lutr_cube_free.restype = None
     lib.lutr_ctx_create.argtypes = [ci, C.POINTER(vp)]

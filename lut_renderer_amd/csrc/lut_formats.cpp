@@ -9,8 +9,11 @@
 // oracle's loop-for-loop restatement (oracle/lut3d_oracle.c) so the tests compare two implementations.
 // All four store the lattice blue-fastest ((r*n+g)*n+b); scale is 1 except for .csp input ranges.
 // Like the .cube reader, non-finite entries are rejected.
+#include <algorithm>
 #include <cctype>
+#include <cfloat>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -141,15 +144,50 @@ int read_m3d(Lines &in, const char *path, std::vector<float> &tab, int &n)
     return LUTR_OK;
 }
 
-// .csp: "CSPLUTV100", "3D", optional METADATA block, per channel {2; in_min in_max; out_min out_max},
-// "n n n", then n^3 triplets RED fastest, each multiplied by (out_max - out_min).  Input ranges
-// become the per-channel scale like .cube's DOMAIN.  A pre-LUT with more than 2 points (a 1D shaper
-// ahead of the cube) is not supported by this engine.
-int read_csp(Lines &in, const char *path, std::vector<float> &tab, int &n, float scale[3])
+// .csp: "CSPLUTV100", "3D", optional METADATA block, per channel either {2; in_min in_max; out_min out_max} or a pre-LUT
+// {npoints; npoints inputs; npoints outputs} (monotonic), then "n n n" and n^3 triplets RED fastest, each multiplied by
+// (out_max - out_min).  Without pre-LUTs the input ranges become the per-channel scale like .cube's DOMAIN.  With one on
+// every channel lut3d resamples it to 65536 uniform entries (its prelut: a 1D shaper applied to the normalised sample ahead of
+// the cube; the mix of the resampling lerp is the UNNORMALISED distance x - in[idx], as in FFmpeg) and the scale is 1.
+constexpr int kPrelutSize = 65536;
+
+struct Prelut { std::vector<float> tab; float vmin[3], vscale[3]; int size = 0; };
+
+int nearest_sample_index(const std::vector<float> &data, float x, int low, int hi)
+{
+    if (x < data[low]) return low;
+    if (x > data[hi]) return hi;
+    while (hi - low > 1) {
+        const int mid = (low + hi) / 2;
+        if (x < data[mid]) hi = mid;
+        else low = mid;
+    }
+    return low;
+}
+
+// bit tests: this file is compiled with -fno-honor-nans, where isnan / v != v may be folded away
+bool finite_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return (u & 0x7f800000u) != 0x7f800000u; }
+
+float sanitizef(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) {
+        if (u & 0x007fffffu) return 0.0f;                          // NaN
+        return (u & 0x80000000u) ? -FLT_MAX : FLT_MAX;             // +-inf
+    }
+    return f;
+}
+
+// next whitespace-delimited float of the stream (the pre-LUT points may span lines)
+bool next_float(Lines &in, float &v) { return std::fscanf(in.f, "%f", &v) == 1; }
+
+int read_csp(Lines &in, const char *path, std::vector<float> &tab, int &n, float scale[3], Prelut &pre)
 {
     if (!in.record() || !in.starts("CSPLUTV100")) return fail(LUTR_EINVAL, path, "not cineSpace LUT format");
     if (!in.record() || !in.starts("3D")) return fail(LUTR_EINVAL, path, "not 3D LUT format");
     float imin[3] = {0, 0, 0}, imax[3] = {1, 1, 1}, omin[3] = {0, 0, 0}, omax[3] = {1, 1, 1};
+    std::vector<float> pin[3], pout[3];
     bool meta = false;
     for (;;) {
         if (!in.record()) return fail(LUTR_EILSEQ, path, "unexpected EOF");
@@ -159,10 +197,31 @@ int read_csp(Lines &in, const char *path, std::vector<float> &tab, int &n, float
     }
     for (int c = 0; c < 3; c++) {
         const long npoints = std::strtol(in.buf, nullptr, 0);
-        if (npoints > 2) return fail(LUTR_EINVAL, path, "cineSpace pre-LUT shapers (more than 2 points) are not supported");
-        if (npoints != 2) return fail(LUTR_EILSEQ, path, "unsupported number of pre-lut points");
-        if (!in.record() || std::sscanf(in.buf, "%f %f", &imin[c], &imax[c]) != 2) return fail(LUTR_EILSEQ, path, "invalid data");
-        if (!in.record() || std::sscanf(in.buf, "%f %f", &omin[c], &omax[c]) != 2) return fail(LUTR_EILSEQ, path, "invalid data");
+        if (npoints > 2) {
+            if (npoints > kPrelutSize) return fail(LUTR_EINVAL, path, "prelut size too large");
+            pin[c].resize((size_t)npoints); pout[c].resize((size_t)npoints);
+            imin[c] = omin[c] = FLT_MAX; imax[c] = omax[c] = -FLT_MAX;
+            float v, last = 0.0f;
+            for (long j = 0; j < npoints; j++) {
+                if (!next_float(in, v) || !finite_bits(v)) return fail(LUTR_EILSEQ, path, "invalid data");
+                imin[c] = std::min(imin[c], v); imax[c] = std::max(imax[c], v);
+                pin[c][(size_t)j] = v;
+                if (j > 0 && v < last) return fail(LUTR_EILSEQ, path, "invalid file has non-monotonic pre-lut");
+                last = v;
+            }
+            for (long j = 0; j < npoints; j++) {
+                if (!next_float(in, v) || !finite_bits(v)) return fail(LUTR_EILSEQ, path, "invalid data");
+                omin[c] = std::min(omin[c], v); omax[c] = std::max(omax[c], v);
+                pout[c][(size_t)j] = v;
+                if (j > 0 && v < last) return fail(LUTR_EILSEQ, path, "invalid file has non-monotonic pre-lut");
+                last = v;
+            }
+        } else if (npoints == 2) {
+            if (!in.record() || std::sscanf(in.buf, "%f %f", &imin[c], &imax[c]) != 2) return fail(LUTR_EILSEQ, path, "invalid data");
+            if (!in.record() || std::sscanf(in.buf, "%f %f", &omin[c], &omax[c]) != 2) return fail(LUTR_EILSEQ, path, "invalid data");
+        } else {
+            return fail(LUTR_EILSEQ, path, "unsupported number of pre-lut points");
+        }
         if (!in.record()) return fail(LUTR_EILSEQ, path, "unexpected EOF");
     }
     int sr, sg, sb;
@@ -181,6 +240,26 @@ int read_csp(Lines &in, const char *path, std::vector<float> &tab, int &n, float
         float *dst = &tab[((r * n + g) * n + b) * 3];
         for (int c = 0; c < 3; c++) dst[c] = v[c] * (omax[c] - omin[c]);
     }
+    if (!pin[0].empty() && !pin[1].empty() && !pin[2].empty()) {
+        pre.size = kPrelutSize;
+        pre.tab.resize((size_t)3 * kPrelutSize);
+        for (int c = 0; c < 3; c++) {
+            const int np = (int)pin[c].size();
+            pre.vmin[c] = imin[c];
+            pre.vscale[c] = (1.0f / (float)(imax[c] - imin[c])) * (float)(kPrelutSize - 1);
+            for (int i = 0; i < kPrelutSize; i++) {
+                float mix = (float)i / (float)(kPrelutSize - 1);
+                const float x = imin[c] + (imax[c] - imin[c]) * mix;                 // lerpf(in_min, in_max, mix)
+                int idx = nearest_sample_index(pin[c], x, 0, np - 1);
+                if (idx + 1 >= np) idx = np - 2;
+                const float a = pout[c][(size_t)idx], b = pout[c][(size_t)idx + 1];
+                mix = x - pin[c][(size_t)idx];
+                pre.tab[(size_t)c * kPrelutSize + i] = sanitizef(a + (b - a) * mix);
+            }
+            scale[c] = 1.0f;
+        }
+        return LUTR_OK;
+    }
     for (int c = 0; c < 3; c++) {
         float s = (float)(1.0 / (double)(imax[c] - imin[c]));
         if (!(s == s)) s = 0.f;
@@ -191,7 +270,8 @@ int read_csp(Lines &in, const char *path, std::vector<float> &tab, int &n, float
 
 }  // namespace
 
-extern "C" int lutr_lut_parse(const char *path, float **rgb, int *n, float scale[3])
+extern "C" int lutr_lut_parse_ex(const char *path, float **rgb, int *n, float scale[3], float **prelut, int *prelut_size,
+                                float prelut_min[3], float prelut_scale[3])
 {
     if (!path || !rgb || !n || !scale) {
         lutr::set_error("lutr_lut_parse: null argument");
@@ -199,6 +279,8 @@ extern "C" int lutr_lut_parse(const char *path, float **rgb, int *n, float scale
     }
     *rgb = nullptr;
     *n = 0;
+    if (prelut) *prelut = nullptr;
+    if (prelut_size) *prelut_size = 0;
     const std::string ext = lower_ext(path);
     if (ext == "cube") return lutr_cube_parse(path, rgb, n, scale);
     if (ext != "dat" && ext != "3dl" && ext != "m3d" && ext != "csp") {
@@ -209,18 +291,34 @@ extern "C" int lutr_lut_parse(const char *path, float **rgb, int *n, float scale
     in.f = std::fopen(path, "r");
     if (!in.f) return fail(LUTR_ENOENT, path, "cannot open");
     std::vector<float> tab;
+    Prelut pre;
     int size = 0;
     scale[0] = scale[1] = scale[2] = 1.0f;
     int rc;
     if (ext == "dat") rc = read_dat(in, path, tab, size);
     else if (ext == "3dl") rc = read_3dl(in, path, tab, size);
     else if (ext == "m3d") rc = read_m3d(in, path, tab, size);
-    else rc = read_csp(in, path, tab, size, scale);
+    else rc = read_csp(in, path, tab, size, scale, pre);
     if (rc) return rc;
+    if (pre.size && (!prelut || !prelut_size || !prelut_min || !prelut_scale))
+        return fail(LUTR_EINVAL, path, "the file carries a pre-LUT: read it with lutr_lut_parse_ex and pass it to lutr_ctx_set_prelut");
     float *out = (float *)std::malloc(tab.size() * sizeof(float));
     if (!out) return fail(LUTR_ENOMEM, path, "out of memory");
     std::memcpy(out, tab.data(), tab.size() * sizeof(float));
+    if (pre.size) {
+        float *po = (float *)std::malloc(pre.tab.size() * sizeof(float));
+        if (!po) { std::free(out); return fail(LUTR_ENOMEM, path, "out of memory"); }
+        std::memcpy(po, pre.tab.data(), pre.tab.size() * sizeof(float));
+        *prelut = po;
+        *prelut_size = pre.size;
+        for (int c = 0; c < 3; c++) { prelut_min[c] = pre.vmin[c]; prelut_scale[c] = pre.vscale[c]; }
+    }
     *rgb = out;
     *n = size;
     return LUTR_OK;
+}
+
+extern "C" int lutr_lut_parse(const char *path, float **rgb, int *n, float scale[3])
+{
+    return lutr_lut_parse_ex(path, rgb, n, scale, nullptr, nullptr, nullptr, nullptr);
 }

@@ -179,11 +179,23 @@ struct lutr_ctx {
     // use per depth (index 0: 8 bit, 1: 10 bit) and dropped whenever the lattice changes
     int precision = LUTR_PRECISION_STRICT;
     uint2 *lat16[2] = {nullptr, nullptr};
+    // lut3d's prelut (lutr_ctx_set_prelut): the host copy, and per LUT depth a device table of the lattice coordinate of every
+    // integer code -- the shaper, the scale and the clip folded into one lookup (pre_dev[depth - 8], 3 x pre_entries floats)
+    std::vector<float> prelut;
+    int pre_size = 0;
+    float pre_min[3] = {0, 0, 0}, pre_scale[3] = {0, 0, 0};
+    float *pre_dev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static void drop_lat16(lutr_ctx *c)
 {
     for (auto &p : c->lat16)
+        if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); p = nullptr; }
+}
+
+static void drop_prelut_tables(lutr_ctx *c)
+{
+    for (auto &p : c->pre_dev)
         if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); p = nullptr; }
 }
 
@@ -261,6 +273,7 @@ void lutr_ctx_destroy(lutr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     drop_lat16(c);
+    drop_prelut_tables(c);
     if (c->lat) (void)hipFree(c->lat);
     if (c->stats) (void)hipFree(c->stats);
     if (c->fscratch) (void)hipFree(c->fscratch);
@@ -362,6 +375,8 @@ static int alloc_lattice(lutr_ctx *c, int n, const float scale[3])
         }
     HIP_TRY(hipSetDevice(c->device));
     drop_lat16(c);                   // they describe the previous lattice
+    drop_prelut_tables(c);           // and so does a prelut: it belongs to the LUT file (set it again after the lattice)
+    c->prelut.clear(); c->pre_size = 0;
     const size_t bytes = lutr_lattice_bytes(n);
     if (bytes != c->lat_bytes) {
         if (c->lat) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->lat); c->lat = nullptr; c->lat_bytes = 0; }
@@ -410,6 +425,64 @@ int lutr_ctx_set_lut(lutr_ctx *c, const float *rgb, int n, const float scale[3])
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->lat, host.data(), c->lat_bytes, hipMemcpyHostToDevice));
     c->unit = unit;
+    return LUTR_OK;
+}
+
+int lutr_ctx_set_prelut(lutr_ctx *c, const float *prelut, int size, const float vmin[3], const float vscale[3])
+{
+    if (!c) { set_error("null context"); return LUTR_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    drop_prelut_tables(c);
+    c->prelut.clear(); c->pre_size = 0;
+    if (!prelut || size == 0) return LUTR_OK;
+    if (size < 2 || size > 65536 || !vmin || !vscale) { set_error("prelut size %d outside [2, 65536] or null ranges", size); return LUTR_EINVAL; }
+    for (size_t i = 0; i < (size_t)3 * size; i++)
+        if (!std::isfinite(prelut[i])) { set_error("non-finite prelut value at float %zu", i); return LUTR_EINVAL; }
+    for (int i = 0; i < 3; i++)
+        if (!std::isfinite(vmin[i]) || !std::isfinite(vscale[i])) { set_error("non-finite prelut range"); return LUTR_EINVAL; }
+    c->prelut.assign(prelut, prelut + (size_t)3 * size);
+    c->pre_size = size;
+    std::memcpy(c->pre_min, vmin, sizeof(c->pre_min));
+    std::memcpy(c->pre_scale, vscale, sizeof(c->pre_scale));
+    return LUTR_OK;
+}
+
+// The lattice coordinate of every integer code at this LUT depth with the prelut in front: FFmpeg's
+// prelut_interp_1d_linear on code * (1 / M), then * scale * (n - 1), clipped to [0, n - 1] -- per pixel in FFmpeg, per code here,
+// float for float the same operations (this file is compiled without contraction).  256 entries for 8-bit containers, else 65536.
+static int prelut_table(lutr_ctx *c, int depth, const float **dev, int *entries)
+{
+    *dev = nullptr; *entries = 0;
+    if (!c->pre_size) return LUTR_OK;
+    const int slot = depth - 8;
+    if (slot < 0 || slot > 8) { set_error("prelut: LUT depth %d outside 8..16", depth); return LUTR_EINVAL; }
+    const int ne = depth <= 8 ? 256 : 65536;
+    *entries = ne;
+    if (c->pre_dev[slot]) { *dev = c->pre_dev[slot]; return LUTR_OK; }
+    const int maxi = (1 << depth) - 1, pmax = c->pre_size - 1;
+    const float scale_f = 1.0f / (float)maxi, lut_max = (float)(c->n - 1);
+    std::vector<float> host((size_t)3 * ne);
+    for (int ch = 0; ch < 3; ch++) {
+        const float sc = c->scale[ch] * lut_max;
+        const float *tab = &c->prelut[(size_t)ch * c->pre_size];
+        for (int code = 0; code < ne; code++) {
+            const float s = (float)code * scale_f;
+            const float scaled = (s - c->pre_min[ch]) * c->pre_scale[ch];
+            const float x = scaled < 0.0f ? 0.0f : (scaled > (float)pmax ? (float)pmax : scaled);
+            const int prev = (int)x, next = (prev + 1) < pmax ? prev + 1 : pmax;
+            const float p = tab[prev], nn = tab[next], d = x - (float)prev;
+            const float v = p + (nn - p) * d;
+            const float t = v * sc;
+            host[(size_t)ch * ne + code] = t < 0.0f ? 0.0f : (t > lut_max ? lut_max : t);
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, host.size() * sizeof(float));
+    if (e != hipSuccess) { set_error("hipMalloc(prelut table): %s", hipGetErrorString(e)); return LUTR_ENOMEM; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->pre_dev[slot] = (float *)p;
+    *dev = c->pre_dev[slot];
     return LUTR_OK;
 }
 
@@ -517,9 +590,11 @@ static const uint2 *fast_lattice(lutr_ctx *c, int depth)
     return slot;
 }
 
-static void fill_lut(LutConsts *L, lutr_ctx *c, int depth)
+static int fill_lut(LutConsts *L, lutr_ctx *c, int depth)
 {
     const int maxi = (1 << depth) - 1;
+    const int rc = prelut_table(c, depth, &L->pre, &L->pre_stride);
+    if (rc) return rc;
     L->lat = c->lat;
     L->lat16 = nullptr;
     L->n1 = c->n + 1;
@@ -528,6 +603,7 @@ static void fill_lut(LutConsts *L, lutr_ctx *c, int depth)
     L->scale_f = 1.0f / (float)maxi;
     L->lut_max = (float)(c->n - 1);
     for (int i = 0; i < 3; i++) L->sc[i] = c->scale[i] * L->lut_max;
+    return LUTR_OK;
 }
 
 static int finish_launch(lutr_ctx *c, const char *name)
@@ -555,7 +631,7 @@ int lutr_apply_planar_rgb(lutr_ctx *c, int depth, int interp, int w, int h, int 
         if (!src->data[i] || !dst->data[i]) { set_error("null plane %d", i); return LUTR_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     LutConsts L; PlaneSet P; FrameGeom G{w, h, row0, rows, nframes};
-    fill_lut(&L, c, depth);
+    if (const int rc = fill_lut(&L, c, depth)) return rc;
     fill_planes(&P, src, dst);
     return finish_launch(c, launch_rgb(c->stream, c->variant, L, P, G, depth, interp, c->stats, c->queue));
 }
@@ -582,7 +658,7 @@ int lutr_apply_packed_rgb(lutr_ctx *c, int pfmt, int interp, int w, int h, int n
     }
     HIP_TRY(hipSetDevice(c->device));
     LutConsts L; FrameGeom G{w, h, row0, rows, nframes};
-    fill_lut(&L, c, bits);
+    if (const int rc = fill_lut(&L, c, bits)) return rc;
     PackedSet P;
     P.s = (const uint8_t *)src->data; P.d = (uint8_t *)dst->data;
     P.ss = src->stride; P.ds = dst->stride;
@@ -611,7 +687,7 @@ int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int
         if (!src->data[i] || !dst->data[i]) { set_error("null plane %d", i); return LUTR_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     LutConsts L; PlaneSet P; FrameGeom G{w, h, row0, rows, nframes};
-    fill_lut(&L, c, p->lut_depth);
+    if (const int rc = fill_lut(&L, c, p->lut_depth)) return rc;
     L.lat16 = fast_lattice(c, p->lut_depth);
     fill_planes(&P, src, dst);
     return finish_launch(c, launch_yuv(c->stream, c->variant, L, K, P, G, LUTR_FMT_DEPTH(p->fmt_in),
@@ -649,7 +725,7 @@ int lutr_apply_yuv_dither(lutr_ctx *c, const lutr_yuv_params *p, int interp, int
         c->fscratch_floats = ny + 2 * nc;
     }
     LutConsts L; PlaneSet P; FrameGeom G{w, h, 0, h, nframes};
-    fill_lut(&L, c, p->lut_depth);
+    if (const int rc = fill_lut(&L, c, p->lut_depth)) return rc;
     fill_planes(&P, src, dst);
     FloatPlanes F{c->fscratch, c->fscratch + ny, c->fscratch + ny + nc};
     return finish_launch(c, launch_yuv_dither(c->stream, L, K, P, G, F, LUTR_FMT_DEPTH(p->fmt_in),

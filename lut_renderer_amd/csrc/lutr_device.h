@@ -171,10 +171,15 @@ __device__ __forceinline__ Rgb interp(const F &f, float sr, float sg, float sb)
 template <int INTERP, class F>
 __device__ __forceinline__ Rgb lut3d_px(const LutConsts &L, const F &f, float rc, float gc, float bc)
 {
-    const float xr = rc * L.scale_f, xg = gc * L.scale_f, xb = bc * L.scale_f;
-    const float sr = med3(xr * L.sc[0], 0.0f, L.lut_max);
-    const float sg = med3(xg * L.sc[1], 0.0f, L.lut_max);
-    const float sb = med3(xb * L.sc[2], 0.0f, L.lut_max);
+    float sr, sg, sb;
+    if (L.pre) {         // a prelut (cineSpace shaper): the host folded shaper, scale and clip into one coordinate per integer code
+        sr = L.pre[(int)rc]; sg = L.pre[L.pre_stride + (int)gc]; sb = L.pre[2 * L.pre_stride + (int)bc];
+    } else {
+        const float xr = rc * L.scale_f, xg = gc * L.scale_f, xb = bc * L.scale_f;
+        sr = med3(xr * L.sc[0], 0.0f, L.lut_max);
+        sg = med3(xg * L.sc[1], 0.0f, L.lut_max);
+        sb = med3(xb * L.sc[2], 0.0f, L.lut_max);
+    }
     const Rgb v = interp<INTERP>(f, sr, sg, sb);
     Rgb o;
     o.r = med3(truncf(v.r * L.maxf), 0.0f, L.maxf);

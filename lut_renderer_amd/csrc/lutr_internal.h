@@ -34,6 +34,8 @@ struct LutConsts {
     float lut_max;       // (float)(n-1)
     float maxf;          // (float)(2^depth - 1)
     int   unit;          // 1 when every lattice node is known to lie in [0, 1] (lets the tile kernels drop the output clip)
+    const float *pre;    // lut3d's prelut folded into a per-code table of lattice coordinates (3 x pre_stride floats: the coordinate of
+    int   pre_stride;    // integer code i of channel c is pre[c * pre_stride + i]), or nullptr.  Only the generic / vector kernels read it.
 };
 
 // Constant block of the YUV contract; same fields, same order as the

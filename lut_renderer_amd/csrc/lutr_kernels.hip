@@ -232,6 +232,8 @@ static unsigned grid_for(long long units, unsigned cap = 0x7fffffffu)
 const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const PlaneSet &P,
                        const FrameGeom &G, int depth, int mode, unsigned *stats, unsigned *queue)
 {
+    if (L.pre && variant == VAR_VEC_LDS) variant = VAR_VEC_GLOBAL;     // a prelut: the tile kernels do not read one
+    const bool tiles = L.pre == nullptr;
     const int wide = depth > 8;
     const int pxt = wide ? 8 : 16;
     const long long px = (long long)G.w * G.rows * G.nframes;
@@ -240,12 +242,12 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     for (int c = 0; c < 3 && vec_ok; c++)
         vec_ok = planes_aligned(P, c, 16, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
-    if (vec_ok && ((variant == VAR_AUTO && !small_job(px)) || variant == VAR_VEC_LDS))
+    if (tiles && vec_ok && ((variant == VAR_AUTO && !small_job(px)) || variant == VAR_VEC_LDS))
         return launch_rgb_tile(st, L, P, G, depth, mode, stats, queue);
     // A ragged width on aligned (padded) rows: the fast kernel takes the columns up to the last multiple of
     // its unit, the scalar kernel the few that remain (each pixel is independent, so any split is exact).
     const int wv = G.w / pxt * pxt;
-    if (variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w && !small_job(px) &&
+    if (tiles && variant == VAR_AUTO && !vec_ok && wv > 0 && wv < G.w && !small_job(px) &&
         (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
         (long long)wv * G.rows * G.nframes / pxt < 0x7fffffffll &&
         planes_aligned(P, 0, 16, G.nframes > 1) && planes_aligned(P, 1, 16, G.nframes > 1) &&
@@ -289,7 +291,7 @@ static bool plane_ok(const uint8_t *p, long long stride, long long fstride, long
 static const char *try_tile2(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P, const FrameGeom &G,
                              int din, int dout, int lut_depth, int csx, int csy, int mode, bool fast, unsigned *stats, unsigned *queue)
 {
-    if (getenv("LUTR_NO_TILE2")) return nullptr;
+    if (getenv("LUTR_NO_TILE2") || L.pre) return nullptr;            // (a prelut: generic / vector kernels only)
     const int win = din > 8, wout = dout > 8, pxt = win ? 8 : 16, bh = 1 << csy;
     if (!(mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL)) return nullptr;
     if (G.w % pxt || G.row0 % bh || G.rows % bh || (csx == 0 && csy == 1)) return nullptr;
@@ -324,6 +326,7 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     const int win = din > 8, wout = dout > 8;
     const int pxt = win ? 8 : 16;
     const int bh = 1 << csy;
+    if (L.pre && variant == VAR_VEC_LDS) variant = VAR_VEC_GLOBAL;     // a prelut: the tile kernels do not read one
     if (variant == VAR_VEC_LDS || (variant == VAR_AUTO && !small_job((long long)G.w * G.rows * G.nframes))) {
         if (const char *name = try_tile2(st, L, K, P, G, din, dout, lut_depth, csx, csy, mode, fast, stats, queue)) return name;
         if (variant == VAR_VEC_LDS) return nullptr;          // asked for the tile kernels, and they cannot take this call

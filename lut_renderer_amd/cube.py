@@ -22,11 +22,28 @@ from . import _native
 
 
 @dataclass
+class Prelut:
+    """lut3d's prelut, the 1D shaper a cineSpace .csp file may put ahead of the cube: `table[c, i]`, sampled at
+    `min[c] + i / scale[c]` (FFmpeg's Lut3DPreLut)."""
+    table: np.ndarray      # float32[3, size]
+    min: np.ndarray        # float32[3]
+    scale: np.ndarray      # float32[3]
+
+    def __post_init__(self) -> None:
+        self.table = np.ascontiguousarray(self.table, dtype=np.float32)
+        self.min = np.ascontiguousarray(self.min, dtype=np.float32)
+        self.scale = np.ascontiguousarray(self.scale, dtype=np.float32)
+        if self.table.ndim != 2 or self.table.shape[0] != 3:
+            raise ValueError(f"prelut table shape {self.table.shape}, expected (3, size)")
+
+
+@dataclass
 class CubeLut:
     """A parsed 3D LUT: `table[r, g, b] = (R, G, B)` floats, blue fastest in memory."""
     n: int
     scale: np.ndarray      # float32[3] = clip(1/(DOMAIN_MAX-DOMAIN_MIN), 0, 1)
     table: np.ndarray      # float32[n, n, n, 3]
+    prelut: Optional[Prelut] = None
 
     def __post_init__(self) -> None:
         self.table = np.ascontiguousarray(self.table, dtype=np.float32)
@@ -41,9 +58,25 @@ def read_cube(path) -> CubeLut:
 
 
 def read_lut(path) -> CubeLut:
-    """Parse any 3D LUT file lut3d accepts (.cube, .dat, .3dl, .m3d, .csp without a shaper), picked by
+    """Parse any 3D LUT file lut3d accepts (.cube, .dat, .3dl, .m3d, .csp -- with its pre-LUT, if it has one), picked by
     extension like FFmpeg's file= option.  Raises LutrError."""
-    return _read_with("lutr_lut_parse", path)
+    lib = _native.load()
+    rgb, pre = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+    n, psize = C.c_int(0), C.c_int(0)
+    scale, pmin, pscale = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    _native.check(lib.lutr_lut_parse_ex(str(path).encode(), C.byref(rgb), C.byref(n), scale, C.byref(pre), C.byref(psize),
+                                        pmin, pscale))
+    try:
+        table = np.ctypeslib.as_array(rgb, shape=(n.value ** 3 * 3,)).astype(np.float32, copy=True)
+        prelut = None
+        if psize.value > 0:
+            pt = np.ctypeslib.as_array(pre, shape=(3 * psize.value,)).astype(np.float32, copy=True)
+            prelut = Prelut(pt.reshape(3, psize.value), np.array(list(pmin), np.float32), np.array(list(pscale), np.float32))
+    finally:
+        lib.lutr_cube_free(rgb)
+        if psize.value > 0:
+            lib.lutr_cube_free(pre)
+    return CubeLut(n.value, np.array(list(scale), dtype=np.float32), table.reshape(n.value, n.value, n.value, 3), prelut)
 
 
 def _read_with(symbol: str, path) -> CubeLut:

@@ -155,6 +155,19 @@ class LutEngine:
         _native.check(self._lib.lutr_ctx_set_lut(
             self._ctx, table.ctypes.data_as(C.POINTER(C.c_float)), int(lut.n), scale))
         self.n, self.scale = int(lut.n), np.array(lut.scale, dtype=np.float32)
+        self.set_prelut(getattr(lut, "prelut", None))
+
+    def set_prelut(self, pre) -> None:
+        """lut3d's prelut (a cineSpace shaper, `cube.Prelut`) for the lattice just set, or None to remove it.  Uploading a
+        lattice drops the prelut of the previous one."""
+        if pre is None:
+            _native.check(self._lib.lutr_ctx_set_prelut(self._ctx, None, 0, None, None))
+            return
+        table = np.ascontiguousarray(pre.table, dtype=np.float32)
+        pmin = (C.c_float * 3)(*[float(v) for v in pre.min])
+        pscale = (C.c_float * 3)(*[float(v) for v in pre.scale])
+        _native.check(self._lib.lutr_ctx_set_prelut(
+            self._ctx, table.ctypes.data_as(C.POINTER(C.c_float)), int(table.shape[1]), pmin, pscale))
 
     def load_cube(self, path) -> CubeLut:
         lut = read_lut(path)
@@ -189,6 +202,22 @@ class LutEngine:
         if rank != src:
             torch.cuda.current_stream(self.device).synchronize()
             _native.check(self._lib.lutr_ctx_lut_seal(self._ctx))      # finiteness + value range of what arrived
+        # a cineSpace prelut travels with the lattice: its size first (0 = none), then table and ranges in one tensor
+        pre = getattr(lut, "prelut", None) if rank == src else None
+        size = torch.tensor([0 if pre is None else int(pre.table.shape[1])], dtype=torch.int32, device=self.device)
+        dist.broadcast(size, src=src, group=group)
+        nsz = int(size.item())
+        if nsz:
+            from .cube import Prelut
+            if rank == src:
+                flat = np.concatenate([pre.table.reshape(-1), pre.min, pre.scale]).astype(np.float32)
+                buf = torch.from_numpy(flat).to(self.device)
+            else:
+                buf = torch.empty(3 * nsz + 6, dtype=torch.float32, device=self.device)
+            dist.broadcast(buf, src=src, group=group)
+            if rank != src:
+                host = buf.cpu().numpy()
+                self.set_prelut(Prelut(host[:3 * nsz].reshape(3, nsz), host[3 * nsz:3 * nsz + 3], host[3 * nsz + 3:]))
 
     # -- control ----------------------------------------------------------
     def set_variant(self, name: str) -> None:

@@ -74,6 +74,7 @@ class LutEngineGroup:
             _native.check(self._lib.lutr_lut_broadcast(arr, len(self.engines), 0))
             for e in self.engines[1:]:
                 e.n, e.scale = root.n, np.array(root.scale, dtype=np.float32)
+                e.set_prelut(getattr(lut, "prelut", None))         # host-side state: it does not travel with the lattice copy
 
     def load_cube(self, path) -> CubeLut:
         lut = read_lut(path)

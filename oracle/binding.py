@@ -21,7 +21,18 @@ RANGE = {"tv": 0, "pc": 1}
 
 
 class OrcLut(C.Structure):
-    _fields_ = [("n", C.c_int), ("scale", C.c_float * 3), ("rgb", C.POINTER(C.c_float))]
+    _fields_ = [("n", C.c_int), ("scale", C.c_float * 3), ("rgb", C.POINTER(C.c_float)),
+                ("pre_size", C.c_int), ("pre_min", C.c_float * 3), ("pre_scale", C.c_float * 3),
+                ("prelut", C.POINTER(C.c_float))]
+
+
+class Prelut:
+    """lut3d's 1D shaper ahead of the cube (cineSpace .csp): table[3, size], sampled at min[c] + i / scale[c]."""
+
+    def __init__(self, table, vmin, scale):
+        self.table = np.ascontiguousarray(table, dtype=np.float32)
+        self.min = np.asarray(vmin, dtype=np.float32)
+        self.scale = np.asarray(scale, dtype=np.float32)
 
 
 class YuvConsts(C.Structure):
@@ -97,7 +108,12 @@ def parse_lut_file(path):
     return _parse_with("orc_lut_file_parse", path)
 
 
-def _parse_with(symbol, path):
+def parse_lut_file_ex(path):
+    """parse_lut_file plus the file's prelut (a Prelut, or None): (n, scale, table, prelut)."""
+    return _parse_with("orc_lut_file_parse", path, want_prelut=True)
+
+
+def _parse_with(symbol, path, want_prelut=False):
     lib = load()
     lut = OrcLut()
     rc = getattr(lib, symbol)(str(path).encode(), C.byref(lut))
@@ -107,19 +123,33 @@ def _parse_with(symbol, path):
         n = lut.n
         table = np.ctypeslib.as_array(lut.rgb, shape=(n * n * n * 3,)).astype(np.float32, copy=True)
         scale = np.array(list(lut.scale), dtype=np.float32)
+        pre = None
+        if lut.pre_size > 0:
+            pt = np.ctypeslib.as_array(lut.prelut, shape=(3 * lut.pre_size,)).astype(np.float32, copy=True)
+            pre = Prelut(pt.reshape(3, lut.pre_size), list(lut.pre_min), list(lut.pre_scale))
     finally:
         lib.orc_lut_free(C.byref(lut))
+    if want_prelut:
+        return n, scale, table.reshape(n, n, n, 3), pre
+    if pre is not None:
+        raise OracleError(-22)        # a caller that cannot carry the prelut must not silently drop it
     return n, scale, table.reshape(n, n, n, 3)
 
 
-def _lut_struct(table: np.ndarray, scale) -> tuple:
+def _lut_struct(table: np.ndarray, scale, prelut=None) -> tuple:
     table = np.ascontiguousarray(table, dtype=np.float32)
     lut = OrcLut()
     lut.n = table.shape[0]
     for i in range(3):
         lut.scale[i] = float(scale[i])
     lut.rgb = table.ctypes.data_as(C.POINTER(C.c_float))
-    return lut, table      # keep `table` alive alongside the struct
+    if prelut is not None:
+        lut.pre_size = prelut.table.shape[1]
+        for i in range(3):
+            lut.pre_min[i] = float(prelut.min[i])
+            lut.pre_scale[i] = float(prelut.scale[i])
+        lut.prelut = prelut.table.ctypes.data_as(C.POINTER(C.c_float))
+    return lut, (table, prelut)      # keep the arrays alive alongside the struct
 
 
 def _plane_args(planes):
@@ -128,8 +158,8 @@ def _plane_args(planes):
     return ptrs, strides
 
 
-def apply_pixel(table, scale, depth: int, interp: str, rgb) -> tuple:
-    lut, _keep = _lut_struct(table, scale)
+def apply_pixel(table, scale, depth: int, interp: str, rgb, prelut=None) -> tuple:
+    lut, _keep = _lut_struct(table, scale, prelut)
     inp = (C.c_int * 3)(*[int(v) for v in rgb])
     out = (C.c_int * 3)()
     rc = load().orc_apply_pixel(C.byref(lut), depth, INTERP[interp], inp, out)
@@ -138,9 +168,9 @@ def apply_pixel(table, scale, depth: int, interp: str, rgb) -> tuple:
     return tuple(out)
 
 
-def apply_rgb(table, scale, depth: int, interp: str, planes, nthreads: int = 1):
+def apply_rgb(table, scale, depth: int, interp: str, planes, nthreads: int = 1, prelut=None):
     """planes: (G, B, R) arrays [H,W] uint8 (depth 8) or uint16; returns new (G, B, R)."""
-    lut, _keep = _lut_struct(table, scale)
+    lut, _keep = _lut_struct(table, scale, prelut)
     src = [np.ascontiguousarray(p) for p in planes]
     dst = [np.empty_like(p) for p in src]
     h, w = src[0].shape
@@ -189,7 +219,7 @@ def yuv_constants(matrix_in="bt709", range_in="tv", matrix_out=None, range_out="
 
 
 def apply_yuv(table, scale, interp: str, consts: YuvConsts, din: int, dl: int, dout: int,
-              csx: int, csy: int, planes, nthreads: int = 1, dither: str = "none", fast: bool = False):
+              csx: int, csy: int, planes, nthreads: int = 1, dither: str = "none", fast: bool = False, prelut=None):
     """planes: (Y, Cb, Cr) arrays; returns new (Y, Cb, Cr) with the output container dtype.
     dither="error_diffusion": Floyd-Steinberg on the final quantisation (orc_apply_yuv_dither).
     fast=True: the product's tolerance-bounded FAST variant (orc_apply_yuv_fast), not FFmpeg's arithmetic."""
@@ -197,7 +227,9 @@ def apply_yuv(table, scale, interp: str, consts: YuvConsts, din: int, dl: int, d
         raise ValueError(dither)
     if fast and dither != "none":
         raise ValueError("the fast variant has no dither path")
-    lut, _keep = _lut_struct(table, scale)
+    if fast and prelut is not None:
+        raise ValueError("the fast variant has no prelut path")
+    lut, _keep = _lut_struct(table, scale, prelut)
     src = [np.ascontiguousarray(p) for p in planes]
     odt = np.uint8 if dout <= 8 else np.uint16
     dst = [np.zeros(p.shape, dtype=odt) for p in src]

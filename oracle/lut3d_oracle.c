@@ -20,6 +20,7 @@
 #include "lut3d_oracle.h"
 
 #include <ctype.h>
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -153,6 +154,9 @@ void orc_lut_free(orc_lut *lut)
         free(lut->rgb);
         lut->rgb = NULL;
         lut->n = 0;
+        free(lut->prelut);
+        lut->prelut = NULL;
+        lut->pre_size = 0;
     }
 }
 
@@ -270,46 +274,117 @@ done:
     return rc;
 }
 
-/* cineSpace .csp, the branch without a pre-LUT (2 points per channel = input / output ranges).  A file
- * with a real shaper (npoints > 2) needs lut3d's prelut stage, which this engine does not have: EINVAL. */
+/* cineSpace .csp [FFmpeg-recall: vf_lut3d.c parse_cinespace].  Per channel either 2 points (input / output ranges) or a
+ * pre-LUT of up to 65536 monotonic points; when all three channels have one, lut3d resamples it to 65536 uniform entries
+ * (nearest_sample_index + lerpf with the UNNORMALISED distance `x - in[idx]` as the mix, as FFmpeg does) and applies it to the
+ * normalised sample before the cube (apply_prelut below). */
+#define PRELUT_SIZE 65536
+
+static inline float lerpf(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
+
+static int nearest_sample_index(const float *data, float x, int low, int hi)
+{
+    int mid;
+    if (x < data[low]) return low;
+    if (x > data[hi]) return hi;
+    for (;;) {
+        if (hi - low <= 1) return low;
+        mid = (low + hi) / 2;
+        if (x < data[mid]) hi = mid;
+        else low = mid;
+    }
+}
+
+static float sanitizef(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) {
+        if (u & 0x007fffffu) return 0.0f;                 /* NaN */
+        return (u & 0x80000000u) ? -FLT_MAX : FLT_MAX;    /* +-inf */
+    }
+    return f;
+}
+
+static int next_float(FILE *f, float *v)
+{
+    return fscanf(f, "%f", v) == 1;
+}
+
 static int parse_cinespace(FILE *f, orc_lut *out)
 {
     char line[MAX_LINE_SIZE];
     float in_min[3] = {0.0f, 0.0f, 0.0f}, in_max[3] = {1.0f, 1.0f, 1.0f};
     float out_min[3] = {0.0f, 0.0f, 0.0f}, out_max[3] = {1.0f, 1.0f, 1.0f};
-    int inside_metadata = 0, size, rc = 0;
+    int inside_metadata = 0, size, rc = 0, prelut = 0;
+    int prelut_sizes[3] = {0, 0, 0};
+    float *in_prelut[3] = {NULL, NULL, NULL}, *out_prelut[3] = {NULL, NULL, NULL};
 
-    NEXT_LINE(skip_line(line));
-    if (strncmp(line, "CSPLUTV100", 10)) return ORC_EINVAL;
-    NEXT_LINE(skip_line(line));
-    if (strncmp(line, "3D", 2)) return ORC_EINVAL;
+#define CSP_FAIL(code) do { rc = (code); goto done; } while (0)
+#undef NEXT_LINE_CSP
+#define NEXT_LINE_CSP() do { \
+        do { if (!fgets(line, sizeof(line), f)) CSP_FAIL(ORC_EILSEQ); } while (skip_line(line)); \
+    } while (0)
+    NEXT_LINE_CSP();
+    if (strncmp(line, "CSPLUTV100", 10)) CSP_FAIL(ORC_EINVAL);
+    NEXT_LINE_CSP();
+    if (strncmp(line, "3D", 2)) CSP_FAIL(ORC_EINVAL);
     while (1) {
-        NEXT_LINE(skip_line(line));
+        NEXT_LINE_CSP();
         if (!strncmp(line, "BEGIN METADATA", 14)) { inside_metadata = 1; continue; }
         if (!strncmp(line, "END METADATA", 12)) { inside_metadata = 0; continue; }
         if (inside_metadata == 0) {
             int size_r, size_g, size_b;
             for (int i = 0; i < 3; i++) {
                 int npoints = (int)strtol(line, NULL, 0);
-                if (npoints > 2) return ORC_EINVAL;                 /* shaper: unsupported here */
-                if (npoints != 2) return ORC_EILSEQ;
-                NEXT_LINE(skip_line(line));
-                if (sscanf(line, "%f %f", &in_min[i], &in_max[i]) != 2) return ORC_EILSEQ;
-                NEXT_LINE(skip_line(line));
-                if (sscanf(line, "%f %f", &out_min[i], &out_max[i]) != 2) return ORC_EILSEQ;
-                NEXT_LINE(skip_line(line));
+                if (npoints > 2) {
+                    float v, last = 0.0f;
+                    if (npoints > PRELUT_SIZE) CSP_FAIL(ORC_EINVAL);
+                    if (in_prelut[i] || out_prelut[i]) CSP_FAIL(ORC_EINVAL);
+                    in_prelut[i] = (float *)malloc((size_t)npoints * sizeof(float));
+                    out_prelut[i] = (float *)malloc((size_t)npoints * sizeof(float));
+                    if (!in_prelut[i] || !out_prelut[i]) CSP_FAIL(ORC_ENOMEM);
+                    prelut_sizes[i] = npoints;
+                    in_min[i] = FLT_MAX; in_max[i] = -FLT_MAX;
+                    out_min[i] = FLT_MAX; out_max[i] = -FLT_MAX;
+                    for (int j = 0; j < npoints; j++) {
+                        if (!next_float(f, &v)) CSP_FAIL(ORC_EILSEQ);
+                        in_min[i] = v < in_min[i] ? v : in_min[i];
+                        in_max[i] = v > in_max[i] ? v : in_max[i];
+                        in_prelut[i][j] = v;
+                        if (j > 0 && v < last) CSP_FAIL(ORC_EILSEQ);     /* "Invalid file has non-monotonic pre-lut" */
+                        last = v;
+                    }
+                    for (int j = 0; j < npoints; j++) {
+                        if (!next_float(f, &v)) CSP_FAIL(ORC_EILSEQ);
+                        out_min[i] = v < out_min[i] ? v : out_min[i];
+                        out_max[i] = v > out_max[i] ? v : out_max[i];
+                        out_prelut[i][j] = v;
+                        if (j > 0 && v < last) CSP_FAIL(ORC_EILSEQ);
+                        last = v;
+                    }
+                } else if (npoints == 2) {
+                    NEXT_LINE_CSP();
+                    if (sscanf(line, "%f %f", &in_min[i], &in_max[i]) != 2) CSP_FAIL(ORC_EILSEQ);
+                    NEXT_LINE_CSP();
+                    if (sscanf(line, "%f %f", &out_min[i], &out_max[i]) != 2) CSP_FAIL(ORC_EILSEQ);
+                } else {
+                    CSP_FAIL(ORC_EILSEQ);
+                }
+                NEXT_LINE_CSP();
             }
-            if (sscanf(line, "%d %d %d", &size_r, &size_g, &size_b) != 3) return ORC_EILSEQ;
-            if (size_r != size_g || size_r != size_b) return ORC_EILSEQ;
+            if (sscanf(line, "%d %d %d", &size_r, &size_g, &size_b) != 3) CSP_FAIL(ORC_EILSEQ);
+            if (size_r != size_g || size_r != size_b) CSP_FAIL(ORC_EILSEQ);
             size = size_r;
+            if (prelut_sizes[0] && prelut_sizes[1] && prelut_sizes[2]) prelut = 1;
             if ((rc = alloc_lut(out, size)))
                 goto done;
             for (int k = 0; k < size; k++)
                 for (int j = 0; j < size; j++)
                     for (int i = 0; i < size; i++) {
                         float *vec = &out->rgb[(((size_t)i * size + j) * size + k) * 3];
-                        NEXT_LINE(skip_line(line));
-                        if (sscanf(line, "%f %f %f", &vec[0], &vec[1], &vec[2]) != 3) { rc = ORC_EILSEQ; goto done; }
+                        NEXT_LINE_CSP();
+                        if (sscanf(line, "%f %f %f", &vec[0], &vec[1], &vec[2]) != 3) CSP_FAIL(ORC_EILSEQ);
                         vec[0] *= out_max[0] - out_min[0];
                         vec[1] *= out_max[1] - out_min[1];
                         vec[2] *= out_max[2] - out_min[2];
@@ -317,15 +392,39 @@ static int parse_cinespace(FILE *f, orc_lut *out)
             break;
         }
     }
-    for (int c = 0; c < 3; c++) {
-        float s = (float)(1. / (in_max[c] - in_min[c]));
-        if (s < 0.f) s = 0.f;
-        if (s > 1.f) s = 1.f;
-        if (s != s) s = 0.f;
-        out->scale[c] = s;
+    if (prelut) {
+        out->prelut = (float *)malloc((size_t)3 * PRELUT_SIZE * sizeof(float));
+        if (!out->prelut) CSP_FAIL(ORC_ENOMEM);
+        out->pre_size = PRELUT_SIZE;
+        for (int c = 0; c < 3; c++) {
+            out->pre_min[c] = in_min[c];
+            out->pre_scale[c] = (1.0f / (float)(in_max[c] - in_min[c])) * (float)(PRELUT_SIZE - 1);
+            for (int i = 0; i < PRELUT_SIZE; ++i) {
+                float mix = (float)i / (float)(PRELUT_SIZE - 1);
+                const float x = lerpf(in_min[c], in_max[c], mix);
+                int idx = nearest_sample_index(in_prelut[c], x, 0, prelut_sizes[c] - 1);
+                float a, b;
+                if (idx + 1 >= prelut_sizes[c]) idx = prelut_sizes[c] - 2;      /* FFmpeg asserts idx + 1 < npoints */
+                a = out_prelut[c][idx + 0];
+                b = out_prelut[c][idx + 1];
+                mix = x - in_prelut[c][idx];
+                out->prelut[(size_t)c * PRELUT_SIZE + i] = sanitizef(lerpf(a, b, mix));
+            }
+            out->scale[c] = 1.00f;
+        }
+    } else {
+        for (int c = 0; c < 3; c++) {
+            float s = (float)(1. / (in_max[c] - in_min[c]));
+            if (s < 0.f) s = 0.f;
+            if (s > 1.f) s = 1.f;
+            if (s != s) s = 0.f;
+            out->scale[c] = s;
+        }
     }
 done:
+    for (int c = 0; c < 3; c++) { free(in_prelut[c]); free(out_prelut[c]); }
     return rc;
+#undef CSP_FAIL
 }
 
 /* lut3d's config: the parser is chosen by the (case-insensitive) extension; none / unknown -> EINVAL */
@@ -379,7 +478,6 @@ static inline rgbvec node(const orc_lut *l, int r, int g, int b)
  * sum is exact; with .5f the sum would round up to the next integer for x = k + 0.49999997 (the float below k + 1/2). */
 #define NEAR(x) ((int)((double)(x) + .5))
 
-static inline float lerpf(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
 
 static inline rgbvec lerp(rgbvec a, rgbvec b, float f)
 {
@@ -558,12 +656,38 @@ static inline int quant(float v, float maxf, int maxi)
     return i;
 }
 
+/* [FFmpeg-recall: vf_lut3d.c prelut_interp_1d_linear / apply_prelut] the shaper ahead of the cube, on the normalised sample */
+static inline float prelut_interp_1d_linear(const orc_lut *l, int idx, float s)
+{
+    const int lut_max = l->pre_size - 1;
+    const float scaled = (s - l->pre_min[idx]) * l->pre_scale[idx];
+    const float x = clipf(scaled, 0.0f, (float)lut_max);
+    const int prev = PREV(x);
+    const int next = ((int)(x) + 1) < lut_max ? ((int)(x) + 1) : lut_max;
+    const float p = l->prelut[(size_t)idx * l->pre_size + prev];
+    const float n = l->prelut[(size_t)idx * l->pre_size + next];
+    const float d = x - (float)prev;
+    return lerpf(p, n, d);
+}
+
+static inline rgbvec apply_prelut(const orc_lut *l, rgbvec s)
+{
+    rgbvec c;
+    if (l->pre_size <= 0 || !l->prelut)
+        return s;
+    c.r = prelut_interp_1d_linear(l, 0, s.r);
+    c.g = prelut_interp_1d_linear(l, 1, s.g);
+    c.b = prelut_interp_1d_linear(l, 2, s.b);
+    return c;
+}
+
 /* one pixel of the A.3 pipeline: integer codes in, integer codes out */
 static inline void lut_pixel(const orc_lut *l, int mode, float scale_f, const float scale_c[3],
                              float lut_max, float maxf, int maxi,
                              int r, int g, int b, int *ro, int *go, int *bo)
 {
-    const rgbvec rgb = {(float)r * scale_f, (float)g * scale_f, (float)b * scale_f};
+    const rgbvec rgb0 = {(float)r * scale_f, (float)g * scale_f, (float)b * scale_f};
+    const rgbvec rgb = apply_prelut(l, rgb0);
     const rgbvec s = {clipf(rgb.r * scale_c[0], 0, lut_max),
                       clipf(rgb.g * scale_c[1], 0, lut_max),
                       clipf(rgb.b * scale_c[2], 0, lut_max)};

@@ -41,10 +41,15 @@ typedef struct orc_lut {
     int    n;          /* lutsize, 2..256 */
     float  scale[3];   /* r,g,b : clip(1/(max-min),0,1) */
     float *rgb;        /* n*n*n*3 floats, index ((r*n+g)*n+b)*3 + c  (blue fastest) */
+    /* lut3d's prelut (a 1D shaper ahead of the cube; only cineSpace .csp files carry one).  pre_size 0 = none, else 65536:
+     * prelut[c * pre_size + i], sampled at pre_min[c] + i / pre_scale[c] (FFmpeg Lut3DPreLut). */
+    int    pre_size;
+    float  pre_min[3], pre_scale[3];
+    float *prelut;
 } orc_lut;
 
 int  orc_cube_parse(const char *path, orc_lut *out);
-/* any file lut3d reads (.cube .dat .3dl .m3d .csp-without-shaper), by extension */
+/* any file lut3d reads (.cube .dat .3dl .m3d .csp), by extension */
 int  orc_lut_file_parse(const char *path, orc_lut *out);
 void orc_lut_free(orc_lut *lut);
 

@@ -485,3 +485,64 @@ def test_tube_and_windows_across_lattice_sizes(engine, orc, n, precision):
     finally:
         engine.set_precision("strict")
         engine.set_variant("auto")
+
+
+@pytest.mark.gpu
+def test_csp_prelut_parity_on_every_path_that_takes_one(engine, orc, tmp_path):
+    """f4: a cineSpace LUT with a shaper on all three channels (lut3d's prelut).  Planar RGB and fused YUV, generic and vector
+    kernels, 8 and 10 bit, three interpolations: bit-exact against the oracle's apply_prelut + cube.  The tile kernels and the
+    fast precision do not read a prelut -- the router must keep such a LUT away from them."""
+    from tests.test_lut_formats import _csp_with_prelut
+    rng = np.random.default_rng(21)
+    n = 17
+    tab = cube.log709_lattice(n)
+    xs = [np.array([0.0, 0.05, 0.2, 0.5, 0.8, 1.0]), np.linspace(0.0, 1.0, 33), np.array([0.0, 0.3, 0.6, 1.0])]
+    ys = [np.array([0.0, 0.2, 0.45, 0.7, 0.9, 1.0]), np.linspace(0.0, 1.0, 33) ** 0.6, np.array([0.0, 0.25, 0.7, 1.0])]
+    p = tmp_path / "shaped.csp"
+    _csp_with_prelut(p, n, tab, list(zip(xs, ys)))
+    lut = cube.read_lut(p)
+    n2, s2, t2, pre = orc.parse_lut_file_ex(p)
+    assert lut.prelut is not None and np.array_equal(lut.prelut.table, pre.table)
+    engine.set_lut(lut)
+    try:
+        for variant in ("auto", "generic", "vec_global", "vec_lds"):
+            engine.set_variant(variant)
+            for depth, fmt in ((10, "yuv420p10le"), (8, "yuv420p")):
+                dt = np.uint16 if depth > 8 else np.uint8
+                k = orc.yuv_constants(din=depth, dl=depth, dout=depth)
+                src = frames.make_yuv("uniform", 256, 64, depth, 1, 1, k=3)
+                for mode in ("tetrahedral", "trilinear", "nearest"):
+                    got = engine.apply_yuv(_to_dev(src, engine), pix_fmt=fmt, interp=mode)
+                    assert "tile" not in engine.last_kernel, engine.last_kernel
+                    want = orc.apply_yuv(t2, s2, mode, k, depth, depth, depth, 1, 1, src, prelut=pre)
+                    _assert_equal(_to_np(got, dt), want, f"prelut yuv {variant} {fmt} {mode} {engine.last_kernel}")
+                rgb = frames.make_rgb("uniform", 256, 64, depth, k=4)
+                got = engine.apply_rgb(_to_dev(rgb, engine), depth=depth, interp="tetrahedral")
+                assert "tile" not in engine.last_kernel, engine.last_kernel
+                want = orc.apply_rgb(t2, s2, depth, "tetrahedral", rgb, prelut=pre)
+                _assert_equal(_to_np(got, dt), want, f"prelut rgb {variant} {depth}")
+        # a big batch under auto routing would take the tile kernels: with a prelut it must not, and the fast precision falls back
+        engine.set_variant("auto")
+        engine.set_precision("fast")
+        src = frames.make_yuv("natural", 1920, 1080, 10, 1, 1, k=5)
+        dev = [t.unsqueeze(0).repeat(24, 1, 1) for t in _to_dev(src, engine)]
+        got = engine.apply_yuv(dev, pix_fmt="yuv420p10le")
+        assert "tile" not in engine.last_kernel and "fast" not in engine.last_kernel, engine.last_kernel
+        k = orc.yuv_constants(din=10)
+        want = orc.apply_yuv(t2, s2, "tetrahedral", k, 10, 10, 10, 1, 1, src, nthreads=8, prelut=pre)
+        _assert_equal([g[7].cpu().numpy().view(np.uint16) for g in got], want, "prelut batch")
+        # one process, two contexts (LutEngineGroup): the prelut is host-side state and must reach every context
+        from lut_renderer_amd.multigpu import LutEngineGroup
+        with LutEngineGroup([0, 0]) as grp:
+            grp.set_lut(lut)
+            got = grp.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le")
+            _assert_equal(_to_np(got, np.uint16), want, "prelut group")
+        # a new lattice drops the prelut
+        engine.set_precision("strict")
+        engine.set_lut(cube.CubeLut(n, np.ones(3, np.float32), tab))
+        got = engine.apply_yuv(_to_dev(src, engine), pix_fmt="yuv420p10le")
+        want = orc.apply_yuv(tab, np.ones(3, np.float32), "tetrahedral", k, 10, 10, 10, 1, 1, src, nthreads=8)
+        _assert_equal(_to_np(got, np.uint16), want, "prelut dropped")
+    finally:
+        engine.set_precision("strict")
+        engine.set_variant("auto")

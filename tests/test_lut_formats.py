@@ -110,14 +110,13 @@ def test_csp_ranges_metadata_and_red_fastest_order(orc, tmp_path):
     assert np.array_equal(lut.scale, np.array([0.5, 1.0, 0.25], np.float32))     # clip(1/(in_max-in_min), 0, 1)
     want = tab * np.array([1.0, 0.5, 0.75], np.float32)                          # * (out_max - out_min)
     assert np.array_equal(lut.table, want)
-    # a real pre-LUT shaper is refused by both readers
-    p2 = tmp_path / "shaper.csp"
-    p2.write_text("CSPLUTV100\n3D\n\n3\n0.0 0.5 1.0\n0.0 0.4 1.0\n" + text.split("END METADATA\n\n", 1)[1])
-    with pytest.raises(_native.LutrError) as ei:
-        cube.read_lut(p2)
-    assert ei.value.code == _native.EINVAL and "pre-LUT" in ei.value.message
-    with pytest.raises(orc.OracleError):
-        orc.parse_lut_file(p2)
+    # a pre-LUT on ONE channel only: lut3d keeps no prelut (it needs all three), the points still give that channel's ranges
+    p2 = tmp_path / "one_shaper.csp"
+    p2.write_text("CSPLUTV100\n3D\n\n3\n0.0 0.5 2.0\n0.0 0.4 1.0\n" + text.split("END METADATA\n\n", 1)[1].split("\n\n", 1)[1])
+    lut2 = cube.read_lut(p2)
+    assert lut2.prelut is None and np.array_equal(lut2.scale, np.array([0.5, 1.0, 0.25], np.float32))
+    n2, s2, t2, pre2 = orc.parse_lut_file_ex(p2)
+    assert pre2 is None and np.array_equal(s2, lut2.scale) and np.array_equal(t2, lut2.table)
     (tmp_path / "wrong.csp").write_text("CSPLUTV100\n1D\n")
     with pytest.raises(_native.LutrError):
         cube.read_lut(tmp_path / "wrong.csp")
@@ -145,3 +144,84 @@ def test_non_finite_entries_are_rejected_by_the_product(tmp_path):
     with pytest.raises(_native.LutrError) as ei:
         cube.read_lut(tmp_path / "nan.dat")
     assert ei.value.code == _native.EILSEQ
+
+
+def _csp_with_prelut(path, n, tab, shapers):
+    """shapers: per channel (inputs, outputs), monotonic; points wrapped over several lines like real files."""
+    with open(path, "w") as f:
+        f.write("CSPLUTV100\n3D\n\nBEGIN METADATA\nshaper test\nEND METADATA\n\n")
+        for xs, ys in shapers:
+            f.write("%d\n" % len(xs))
+            for vals in (xs, ys):
+                for i in range(0, len(vals), 5):
+                    f.write(" ".join("%.9g" % v for v in vals[i:i + 5]) + "\n")
+        f.write("\n%d %d %d\n" % (n, n, n))
+        f.write("".join("%.9g %.9g %.9g\n" % tuple(v) for v in _rows_red_fastest(tab)))
+
+
+def test_csp_prelut_is_resampled_like_lut3d_and_both_readers_agree(orc, tmp_path):
+    """A cineSpace file with a shaper on all three channels: lut3d resamples it to 65536 uniform entries (`prelut`), sets the
+    scale to 1 and multiplies the cube by (out_max - out_min).  The product's reader and the oracle's must agree float for float,
+    and the resampling is FFmpeg's (lerp with the UNNORMALISED distance as the mix)."""
+    rng = np.random.default_rng(12)
+    n = 5
+    tab = rng.random((n, n, n, 3)).astype(np.float32)
+    xs = [np.array([0.0, 0.1, 0.25, 0.5, 0.75, 1.0, 2.0]), np.linspace(0.0, 1.0, 11), np.array([-0.5, 0.0, 0.5, 1.5])]
+    ys = [np.array([0.0, 0.3, 0.5, 0.7, 0.85, 0.95, 1.0]), np.linspace(0.0, 1.0, 11) ** 0.5, np.array([0.0, 0.2, 0.6, 0.8])]
+    p = tmp_path / "shaped.csp"
+    _csp_with_prelut(p, n, tab, list(zip(xs, ys)))
+    lut = cube.read_lut(p)
+    n2, s2, t2, pre2 = orc.parse_lut_file_ex(p)
+    assert lut.n == n2 == n and lut.prelut is not None and pre2 is not None
+    assert np.array_equal(lut.scale, np.ones(3, np.float32)) and np.array_equal(s2, lut.scale)
+    assert np.array_equal(lut.table, t2)
+    assert np.array_equal(lut.table, tab * np.array([1.0, 1.0, 0.8], np.float32))              # * (out_max - out_min)
+    assert lut.prelut.table.shape == (3, 65536) and np.array_equal(lut.prelut.table, pre2.table)
+    assert np.array_equal(lut.prelut.min, pre2.min) and np.array_equal(lut.prelut.scale, pre2.scale)
+    assert np.array_equal(lut.prelut.min, np.array([0.0, 0.0, -0.5], np.float32))
+    assert np.allclose(lut.prelut.scale, 65535.0 / np.array([2.0, 1.0, 2.0]), rtol=1e-6)
+    # entry i samples x = min + (max - min) * i / 65535; between input points k and k+1 the value is y[k] + (y[k+1] - y[k]) * (x - x[k])
+    for c in range(3):
+        for i in (0, 1, 5000, 20000, 32768, 50000, 65534, 65535):
+            x = np.float32(xs[c][0]) + (np.float32(xs[c][-1]) - np.float32(xs[c][0])) * (np.float32(i) / np.float32(65535))
+            k = min(int(np.searchsorted(xs[c].astype(np.float32), x, side="right")) - 1, len(xs[c]) - 2)
+            k = max(k, 0)
+            a, b = np.float32(ys[c][k]), np.float32(ys[c][k + 1])
+            want = a + (b - a) * (x - np.float32(xs[c][k]))
+            assert lut.prelut.table[c, i] == np.float32(want), (c, i)
+    # the plain entry point refuses to drop the shaper; so does the oracle's three-value reader
+    lib = _native.load()
+    import ctypes as C
+    rgb, nn, sc = C.POINTER(C.c_float)(), C.c_int(0), (C.c_float * 3)()
+    assert lib.lutr_lut_parse(str(p).encode(), C.byref(rgb), C.byref(nn), sc) == _native.EINVAL
+    with pytest.raises(orc.OracleError):
+        orc.parse_lut_file(p)
+    # malformed shapers
+    bad = tmp_path / "nonmono.csp"
+    _csp_with_prelut(bad, n, tab, [(np.array([0.0, 0.6, 0.5, 1.0]), np.array([0.0, 0.3, 0.6, 1.0]))] * 3)
+    with pytest.raises(_native.LutrError):
+        cube.read_lut(bad)
+    with pytest.raises(orc.OracleError):
+        orc.parse_lut_file_ex(bad)
+    short = tmp_path / "short.csp"
+    short.write_text("CSPLUTV100\n3D\n\n4\n0.0 0.5 1.0\n")
+    with pytest.raises(_native.LutrError):
+        cube.read_lut(short)
+
+
+def test_prelut_oracle_pixels(orc, tmp_path):
+    """apply_prelut ahead of the cube, checked by hand on an identity cube: the output code is the shaper's value."""
+    n = 2
+    tab = cube.identity_lattice(n)
+    xs = np.array([0.0, 0.25, 0.5, 1.0]); ys = np.array([0.0, 0.5, 0.75, 1.0])
+    p = tmp_path / "id.csp"
+    _csp_with_prelut(p, n, tab, [(xs, ys)] * 3)
+    n2, s2, t2, pre = orc.parse_lut_file_ex(p)
+    for code in (0, 64, 255, 256, 300, 511, 512, 767, 1023):
+        x = np.float32(code) * (np.float32(1.0) / np.float32(1023))
+        pos = np.float32(np.clip((x - pre.min[0]) * pre.scale[0], 0, 65535))
+        i0 = int(pos); i1 = min(i0 + 1, 65535)
+        v = pre.table[0, i0] + (pre.table[0, i1] - pre.table[0, i0]) * (pos - np.float32(i0))
+        want = int(np.clip(int(np.float32(np.float32(np.clip(v, 0, 1)) * np.float32(1023))), 0, 1023))
+        got = orc.apply_pixel(t2, s2, 10, "trilinear", (code, code, code), prelut=pre)
+        assert abs(got[0] - want) <= 1 and got[0] == got[1] == got[2], (code, got, want)

@@ -24,22 +24,31 @@ par.lutr_cube_free.argtypes = [C.POINTER(C.c_float)]
 par.lutr_cube_free.restype = None
 
 class OrcLut(C.Structure):
-    _fields_ = [("n", C.c_int), ("scale", C.c_float * 3), ("rgb", C.POINTER(C.c_float))]
+    _fields_ = [("n", C.c_int), ("scale", C.c_float * 3), ("rgb", C.POINTER(C.c_float)),
+                ("pre_size", C.c_int), ("pre_min", C.c_float * 3), ("pre_scale", C.c_float * 3), ("prelut", C.POINTER(C.c_float))]
+par.lutr_lut_parse_ex.argtypes = par.lutr_lut_parse.argtypes + [C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int),
+                                                               C.POINTER(C.c_float), C.POINTER(C.c_float)]
 orc.orc_lut_file_parse.argtypes = [C.c_char_p, C.POINTER(OrcLut)]
 orc.orc_lut_free.argtypes = [C.POINTER(OrcLut)]
 orc.orc_lut_free.restype = None
 
 def both(path):
     rgb, n, sc = C.POINTER(C.c_float)(), C.c_int(), (C.c_float * 3)()
-    rc = par.lutr_lut_parse(path.encode(), C.byref(rgb), C.byref(n), sc)
+    pre, psz, pmin, psc = C.POINTER(C.c_float)(), C.c_int(), (C.c_float * 3)(), (C.c_float * 3)()
+    rc = par.lutr_lut_parse_ex(path.encode(), C.byref(rgb), C.byref(n), sc, C.byref(pre), C.byref(psz), pmin, psc)
     if rc == 0:
         a = np.ctypeslib.as_array(rgb, shape=(n.value ** 3 * 3,)).copy()      # touch every float the parser returned
         assert np.isfinite(a).all()
         par.lutr_cube_free(rgb)
+        if psz.value:
+            assert np.isfinite(np.ctypeslib.as_array(pre, shape=(3 * psz.value,)).copy()).all()
+            par.lutr_cube_free(pre)
     lut = OrcLut()
     rc2 = orc.orc_lut_file_parse(path.encode(), C.byref(lut))
     if rc2 == 0:
         np.ctypeslib.as_array(lut.rgb, shape=(lut.n ** 3 * 3,)).copy()
+        if lut.pre_size:
+            np.ctypeslib.as_array(lut.prelut, shape=(3 * lut.pre_size,)).copy()
         orc.orc_lut_free(C.byref(lut))
     return rc, rc2
 
@@ -58,6 +67,7 @@ good = {
     "a.3dl": "# h\n" + " ".join(str(min(i * 64, 1023)) for i in range(17)) + "\n" + "".join(tri() for _ in range(17 ** 3)),
     "a.m3d": "name x\nin 27\nout 4096\nformat lut\nvalues\tblue\tgreen\tred\n" + "".join(tri() for _ in range(27)),
     "a.csp": "CSPLUTV100\n3D\n\n2\n0.0 1.0\n0.0 1.0\n2\n0.0 1.0\n0.0 1.0\n2\n0.0 1.0\n0.0 1.0\n\n3 3 3\n" + ent(27),
+    "b.csp": "CSPLUTV100\n3D\n\n" + "5\n0.0 0.1 0.4\n0.7 1.0\n0.0 0.3 0.6 0.8 1.0\n" * 3 + "\n3 3 3\n" + ent(27),      # pre-LUTs
 }
 n_ok = 0
 for name, text in good.items():
