@@ -546,3 +546,13 @@ def test_csp_prelut_parity_on_every_path_that_takes_one(engine, orc, tmp_path):
     finally:
         engine.set_precision("strict")
         engine.set_variant("auto")
+
+
+@pytest.mark.gpu
+def test_soak_tile_kernels_against_the_generic_kernel_on_the_validity_bounds():
+    """tools/soak.py for a few seconds: chroma swept radially across the tube's bound, luma over the whole range, random lattices,
+    domains, matrices, ranges, formats -- the tile kernels (tube, windows, gather) must equal the scalar kernel bit for bit."""
+    res = subprocess.run([sys.executable, str(ROOT / "tools" / "soak.py"), "8"], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert res.returncode == 0 and "soak ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+    runs = int(res.stdout.split("soak ok:")[1].split("runs")[0])
+    assert runs >= 20, res.stdout

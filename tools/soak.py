@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""tools/soak.py [seconds] -- GPU soak of the window / tube validity logic: tile kernels vs the scalar generic kernel, bit for bit.
+
+The tube and the raw boxes rest on conservative bounds (csrc/lutr_tile2.hip map_box, tube_lane): if a bound were ever too
+optimistic a pixel would read a node that is not staged and come out wrong.  This drives the two kernels with frames built to
+sit ON those bounds -- chroma swept radially from neutral to far outside the tube in every direction, luma uniform over the
+whole code range (clipping included), random lattice sizes, domains, matrices, ranges, formats, depths, interpolations -- and
+compares every sample.  Both sides are the product's strict kernels (GPU against GPU, so sizes can be large); the generic
+kernel is itself pinned against the oracle by tests/.
+"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from lut_renderer_amd import cube  # noqa: E402
+from lut_renderer_amd.engine import LutEngine  # noqa: E402
+
+
+def frame(rng, w, h, depth, csx, csy, full):
+    m = (1 << depth) - 1
+    cw, ch = w >> csx, h >> csy
+    yy, xx = np.mgrid[0:ch, 0:cw].astype(np.float32)
+    theta = rng.uniform(0, 2 * np.pi) + 2 * np.pi * xx / cw * rng.integers(1, 5)
+    rad = (yy / ch) * rng.uniform(0.05, 0.6) * m                       # neutral at the top, far out at the bottom
+    rad = rad + rng.normal(0, rng.choice([0.0, 0.5, 2.0, 8.0]) * (m / 1023.0), size=rad.shape)
+    mid = (m + 1) / 2
+    cb = np.clip(np.rint(mid + rad * np.cos(theta)), 0, m)
+    cr = np.clip(np.rint(mid + rad * np.sin(theta)), 0, m)
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        y = rng.integers(0, m + 1, size=(h, w))
+    elif kind == 1:
+        y = np.clip(np.rint(np.linspace(0, m, w)[None, :] + rng.normal(0, 3, size=(h, w))), 0, m)
+    else:
+        y = np.full((h, w), rng.integers(0, m + 1))
+    dt = np.uint16 if depth > 8 else np.uint8
+    return [y.astype(dt), cb.astype(dt), cr.astype(dt)]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    eng = LutEngine(0)
+    rng = np.random.default_rng(20261004)
+    t0, runs, px, tube_tiles, tiles = time.time(), 0, 0, 0, 0
+    fmts = [("yuv420p10le", 10, 1, 1), ("yuv420p", 8, 1, 1), ("yuv422p10le", 10, 1, 0), ("yuv444p10le", 10, 0, 0), ("yuv444p", 8, 0, 0)]
+    while time.time() - t0 < budget:
+        n = int(rng.choice([22, 26, 29, 33, 33, 33, 37, 40, 41, 65]))
+        lat = rng.uniform(0.0, 1.0, size=(n, n, n, 3)).astype(np.float32) if rng.random() < 0.3 else cube.log709_lattice(n)
+        scale = np.array([1.0, 1.0, 1.0], np.float32) if rng.random() < 0.7 else np.full(3, rng.uniform(0.6, 1.0), np.float32)
+        eng.set_lut(cube.CubeLut(n, scale, lat))
+        fmt, depth, csx, csy = fmts[rng.integers(0, len(fmts))]
+        w, h = int(rng.choice([512, 1024, 1920])), int(rng.choice([64, 136, 270]) * 2)
+        rg = str(rng.choice(["tv", "pc"]))
+        kw = dict(pix_fmt=fmt, interp=str(rng.choice(["tetrahedral", "trilinear"])),
+                  matrix_in=str(rng.choice(["bt709", "bt601", "bt2020nc"])), range_src=rg, range_in=rg)
+        if rng.random() < 0.25:                # the reference's full-range prologue (BASELINE config 5): pc source, tv into an 8-bit LUT
+            kw.update(range_src="pc", range_in="tv", lut_depth=8)
+        src = frame(rng, w, h, depth, csx, csy, kw["range_in"] == "pc")
+        dev = [torch.from_numpy(p.view(np.int16) if p.dtype == np.uint16 else p).to(eng.device).unsqueeze(0).repeat(4, 1, 1) for p in src]
+        eng.set_variant("vec_lds")
+        eng.tile_stats(True)
+        a = [t.clone() for t in eng.apply_yuv(dev, **kw)]
+        st = eng.tile_stats(False)
+        name = eng.last_kernel
+        eng.set_variant("generic")
+        b = eng.apply_yuv(dev, **kw)
+        for i, (x, y) in enumerate(zip(a, b)):
+            if not torch.equal(x, y):
+                d = (x.to(torch.int32) - y.to(torch.int32)).abs()
+                raise SystemExit(f"MISMATCH run {runs}: n={n} {fmt} {kw} {name} plane {i}: {int((d > 0).sum())} samples, max {int(d.max())}")
+        runs += 1
+        px += 4 * w * h
+        tube_tiles += st["tube_tiles"]
+        tiles += st["tiles"]
+    print(f"soak ok: {runs} runs, {px / 1e6:.0f} Mpx compared, {tiles} tiles ({tube_tiles} through the tube), {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
