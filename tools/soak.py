@@ -5,7 +5,7 @@ The tube and the raw boxes rest on conservative bounds (csrc/lutr_tile2.hip map_
 optimistic a pixel would read a node that is not staged and come out wrong.  This drives the two kernels with frames built to
 sit ON those bounds -- chroma swept radially from neutral to far outside the tube in every direction, luma uniform over the
 whole code range (clipping included), random lattice sizes, domains, matrices, ranges, formats, depths, interpolations -- and
-compares every sample.  Both sides are the product's strict kernels (GPU against GPU, so sizes can be large); the generic
+compares every sample (and holds the fast kernels to one code from that).  Both sides are the product's strict kernels (GPU against GPU, so sizes can be large); the generic
 kernel is itself pinned against the oracle by tests/.
 """
 import sys
@@ -44,7 +44,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     eng = LutEngine(0)
     rng = np.random.default_rng(20261004)
-    t0, runs, px, tube_tiles, tiles = time.time(), 0, 0, 0, 0
+    t0, runs, px, tube_tiles, tiles, fast_runs = time.time(), 0, 0, 0, 0, 0
     fmts = [("yuv420p10le", 10, 1, 1), ("yuv420p", 8, 1, 1), ("yuv422p10le", 10, 1, 0), ("yuv444p10le", 10, 0, 0), ("yuv444p", 8, 0, 0)]
     while time.time() - t0 < budget:
         n = int(rng.choice([22, 26, 29, 33, 33, 33, 37, 40, 41, 65]))
@@ -71,11 +71,25 @@ def main():
             if not torch.equal(x, y):
                 d = (x.to(torch.int32) - y.to(torch.int32)).abs()
                 raise SystemExit(f"MISMATCH run {runs}: n={n} {fmt} {kw} {name} plane {i}: {int((d > 0).sum())} samples, max {int(d.max())}")
+        # the fast kernels (their own, wider tube): at most one code from the strict result wherever they run
+        eng.set_variant("vec_lds")
+        eng.set_precision("fast")
+        c = eng.apply_yuv(dev, **kw)
+        eng.set_precision("strict")
+        if "fast" in eng.last_kernel:
+            fast_runs += 1
+            for i, (x, y) in enumerate(zip(c, b)):
+                d = (x.to(torch.int32) - y.to(torch.int32)).abs()
+                # one code at the LUT's depth; behind the 8-bit prologue that is up to 4 codes of a 10-bit output
+                tol = 1 if kw.get("lut_depth", depth) == depth else 4
+                if int(d.max()) > tol:
+                    raise SystemExit(f"FAST MISMATCH run {runs}: n={n} {fmt} {kw} {eng.last_kernel} plane {i}: max {int(d.max())}")
         runs += 1
         px += 4 * w * h
         tube_tiles += st["tube_tiles"]
         tiles += st["tiles"]
-    print(f"soak ok: {runs} runs, {px / 1e6:.0f} Mpx compared, {tiles} tiles ({tube_tiles} through the tube), {time.time() - t0:.0f} s")
+    print(f"soak ok: {runs} runs ({fast_runs} also with the fast kernels), {px / 1e6:.0f} Mpx compared, {tiles} tiles "
+          f"({tube_tiles} through the tube), {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
