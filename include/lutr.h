@@ -234,8 +234,8 @@ int lutr_ctx_set_precision(lutr_ctx *ctx, int precision);
 
 /* ---- tuning / introspection (bench and tests) ---- */
 /* kernel variant: 0 = auto, 1 = generic (scalar, any layout), 2 = vector + global gather,
- * 3 = vector + LDS lattice window (persistent tile kernels).  Auto picks 3 for launches of 95 Mpx and more
- * (about 12 UHD frames), 2 below that (lower latency), 1 for layouts the vector kernels cannot take; a ragged
+ * 3 = vector + LDS lattice window (persistent tile kernels).  Auto picks 3 for launches of 70 Mpx and more
+ * (about 8 UHD frames), 2 below that (lower latency), 1 for layouts the vector kernels cannot take; a ragged
  * width on aligned rows is split between 3 and 1.  2 and 3 fail with LUTR_EINVAL on such layouts. */
 int lutr_ctx_set_variant(lutr_ctx *ctx, int variant);
 /* name of the kernel variant the last apply call launched ("" before the first) */

@@ -208,15 +208,14 @@ static bool planes_aligned(const PlaneSet &P, int plane, long long a, bool batch
     return true;
 }
 
-// The persistent tile kernels pay ~40 us before their first pixel is stored (coordinate table, bounds pass,
-// window staging) and end with a tail of partly idle CUs, so they only win on big launches.  UHD yuv420p10le
-// tetrahedral, us per launch, tile / plain vector kernels (taps gathered from L1/L2, 5-8 waves per SIMD):
-// 1 frame 66 / 25, 4 frames 158 / 85, 8 frames 216 / 194, 12 frames 283 / 292, 16 frames 349 / 387, 64 frames
-// 1085 / 1537; one 1080p 8-bit frame 48 / 17 (bench.py --frames N --variant vec_lds|vec_global).  "auto"
-// therefore sends launches under 95 Mpx to the vector kernels.  LUTR_SMALL_JOB_MPX moves the boundary (0 = never).
+// The persistent tile kernels pay ~40 us before their first pixel is stored (coordinate table, tube staging) and end with a tail
+// of partly idle CUs, so they only win on big launches.  Round 2, Gpx/s tile / plain vector kernels (taps gathered from L1/L2,
+// 5-8 waves per SIMD; tools/small_sweep.sh): UHD yuv420p10le 1 frame 114 / 276, 4 frames 250 / 356, 8 frames 336 / 325,
+// 12 frames 386 / 329, 32 frames 524 / 334; 1080p 16 frames 251 / 356, 32 frames (66 Mpx) 340 / 322.  "auto" therefore sends
+// launches under 70 Mpx to the vector kernels.  LUTR_SMALL_JOB_MPX moves the boundary (0 = never).
 static bool small_job(long long px)
 {
-    long long mpx = 95;
+    long long mpx = 70;
     if (const char *e = getenv("LUTR_SMALL_JOB_MPX")) { const long long v = atoll(e); if (v >= 0 && v <= 100000) mpx = v; }
     return px < mpx * 1000000ll;
 }

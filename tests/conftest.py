@@ -5,7 +5,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-# Test frames are tiny; in the product "auto" hands launches under 95 Mpx to the low-latency vector kernels.
+# Test frames are tiny; in the product "auto" hands launches under 70 Mpx to the low-latency vector kernels.
 # The parity tests want the LDS-window tile kernels under "auto", so the boundary is moved to 0 for the test
 # processes (and the workers they start); test_small_jobs_take_the_low_latency_kernels covers the routing.
 import os  # noqa: E402

@@ -744,7 +744,7 @@ def test_contexts_on_concurrent_threads(orc, cube_dir):
 
 
 def test_small_jobs_take_the_low_latency_kernels(engine, orc, cube_dir, monkeypatch):
-    """Under "auto" a launch below the small-job boundary (95 Mpx by default) runs on the plain vector kernels
+    """Under "auto" a launch below the small-job boundary (70 Mpx by default) runs on the plain vector kernels
     (3x lower latency for one 1080p frame), anything larger on the tile kernels; same pixels either way."""
     lut = _load(engine, cube_dir, "log709_33.cube")
     src = frames.natural_yuv(512, 128, 10, 1, 1, k=5)
