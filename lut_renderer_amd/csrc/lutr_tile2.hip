@@ -978,6 +978,9 @@ DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, co
 #ifndef LUTR_T2_PIPE_FAST
 #define LUTR_T2_PIPE_FAST 0
 #endif
+#ifndef LUTR_T2_KARG
+#define LUTR_T2_KARG 1
+#endif
 #ifndef LUTR_T2_TB_FAST
 #define LUTR_T2_TB_FAST 4
 #endif
@@ -1147,6 +1150,15 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         if constexpr (!N::fast) L.maxf = in_vgpr(L_.maxf);
     }
     if (lds_base() != 0) __builtin_trap();        // crd_table8 addresses the table absolutely
+#if LUTR_T2_KARG && defined(__HIP_DEVICE_COMPILE__)
+    {   // pos_at reads the plane descriptors from the kernel-argument segment at the offset a struct of the parameters gives them:
+        // make sure that IS where they are before any address is built from them
+        struct KernArgsChk { LutConsts L; YuvConsts K; Planes2 P; FrameGeom G; Geom TG; };
+        const __attribute__((address_space(4))) Planes2 *chk = (const __attribute__((address_space(4))) Planes2 *)(
+            (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernArgsChk, P));
+        if (chk->s[0] != P.s[0] || chk->d[2] != P.d[2] || chk->ss[1] != P.ss[1] || chk->dfs[2] != P.dfs[2]) __builtin_trap();
+    }
+#endif
     // the per-pixel constants of the table variants, times 8 (crd_table8); map_box keeps the plain ones
     YuvConsts KB = K;
     if constexpr (V >= V_TAB) {
@@ -1227,8 +1239,18 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
                    ystep_s2 = (unsigned)((int)P.ss[2] << lh_log2);
     const unsigned ystep_d0 = (unsigned)((T::BH << lh_log2) * (int)P.ds[0]), ystep_d1 = (unsigned)((int)P.ds[1] << lh_log2),
                    ystep_d2 = (unsigned)((int)P.ds[2] << lh_log2);
+    // The plane bases and frame strides (24 SGPRs) are only needed here, once per chunk: read them from the kernel-argument
+    // segment when they are, instead of keeping them resident (and spilled to VGPR lanes) through every tile
+    // (SGPR spills of the headline kernel 101 -> 82; the layout assumption is checked at kernel start).
     auto pos_at = [&](int f, int tsx, int try_) {
         TilePos q;
+#if LUTR_T2_KARG && defined(__HIP_DEVICE_COMPILE__)
+        struct KernArgs { LutConsts L; YuvConsts K; Planes2 P; FrameGeom G; Geom TG; };   // the kernel's parameter list
+        typedef const __attribute__((address_space(4))) Planes2 *PlanesK;
+        PlanesK Pk = (PlanesK)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KernArgs, P));
+        asm volatile("" : "+s"(Pk));                                      // opaque: the loads stay here, not hoisted out of the loop
+        const Planes2 P = *Pk;
+#endif
         const long long urow0 = cr0 + (try_ << lh_log2);                  // wave-uniform
         q.s0 = P.s[0] + f * P.sfs[0] + urow0 * T::BH * (long long)P.ss[0] + (long long)tsx * lw * YIB;
         q.s1 = P.s[1] + f * P.sfs[1] + urow0 * (long long)P.ss[1] + (long long)tsx * lw * CIB;
