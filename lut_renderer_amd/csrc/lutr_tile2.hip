@@ -512,6 +512,28 @@ DEV bool tube_holds(const YuvConsts &K, const Geom &TG, const Ext &e)
     return __all(worst <= TG.tube_t);
 }
 
+// The same bound sample by sample, for units with at most four chroma samples (4:2:0 and 4:2:2 at 10 bit): a pixel's chroma IS one
+// of them, so no pairing of one sample's Cb with another's Cr inflates the differences.  About the cost of the corner form; under
+// per-sample chroma noise it keeps more tiles in the tube (sigma = 16, strict kernels' H = 6: 17 % -> 32 % of the tiles).
+template <int WIN, int WOUT, int CSX, int CSY, int PRE>
+DEV bool tube_holds_samples(const YuvConsts &K, const Geom &TG, const TileIn<WIN, WOUT, CSX, CSY> &in)
+{
+    using T = Tile<WIN, WOUT, CSX, CSY>;
+    float worst = 0.0f;
+#pragma unroll
+    for (int j = 0; j < T::NC; j++) {
+        float cbv = wsample<WIN>(in.cb, j), crv = wsample<WIN>(in.cr, j);
+        if constexpr (PRE) {
+            cbv = cfloor(fma_(K.pc, cbv, K.pcb), K.pre_max);
+            crv = cfloor(fma_(K.pc, crv, K.pcb), K.pre_max);
+        }
+        const float cbd = cbv - K.coff, crd = crv - K.coff;
+        const float rv = K.krv * crd, gv = fma_(K.kgu, cbd, K.kgv * crd), bu = K.kbu * cbd;
+        worst = vmax3(worst, fabsf(gv - rv), fabsf(bu - rv));
+    }
+    return __all(worst <= TG.tube_t);
+}
+
 // ---------------------------------------------------------------- restage
 DEV uint32_t shx(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 DEV float wave_min(float v) {
@@ -986,6 +1008,9 @@ DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, co
 #ifndef LUTR_T2_KARG
 #define LUTR_T2_KARG 1
 #endif
+#ifndef LUTR_T2_TUBE_SAMPLES
+#define LUTR_T2_TUBE_SAMPLES 1
+#endif
 #ifndef LUTR_T2_TB_FAST
 #define LUTR_T2_TB_FAST 4
 #endif
@@ -1331,7 +1356,12 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             if (legal) {
                 const bool in_rect = __all((pk_subsat_sv(TG.tube_rlo, e.cbmin) | pk_subsat_vs(e.cbmax, TG.tube_rhi) |
                                             pk_subsat_sv(TG.tube_rlo, e.crmin) | pk_subsat_vs(e.crmax, TG.tube_rhi)) == 0u);
-                use_tube = in_rect || tube_holds<WIN, PRE>(K, TG, e);
+                if (in_rect) use_tube = true;
+                // per sample for the strict kernels (their tube is 6 cells wide: sigma = 16 frames +9 %, natural -0.8 %, 3 x chroma
+                // -1.5 %); the fast kernels' 8-cell tube gains 1.7 % there and loses 1.4 % on 3 x chroma: corner form
+                else if constexpr (T::NC <= 4 && V != V_FAST && LUTR_T2_TUBE_SAMPLES)
+                    use_tube = tube_holds_samples<WIN, WOUT, CSX, CSY, PRE>(K, TG, in);
+                else use_tube = tube_holds<WIN, PRE>(K, TG, e);
             }
         }
         bool use_lds = use_tube || box_holds(scratch_off, e);  // first level: raw extremes against the window's raw box
