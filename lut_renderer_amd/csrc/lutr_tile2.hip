@@ -38,6 +38,9 @@
 #include <utility>
 
 #include "lutr_internal.h"
+#ifndef LUTR_NT
+#define LUTR_NT 2        // 1: non-temporal stores, 2: and loads -- frames are read once and written once (+0.9 % / +0.5 % on 4:2:0, +1 % each on 4:4:4)
+#endif
 
 // One translation unit per (input width, output width, chroma layout): the Makefile compiles this file nine times
 // (-DLUTR_T2_WI=.. -DLUTR_T2_WO=.. -DLUTR_T2_X=.. -DLUTR_T2_Y=..), in parallel, each defining launch_yuv_tile2_w<WI><WO>_c<X><Y>.
@@ -282,16 +285,33 @@ DEV void wput(uint32_t *w, int i, float v)
 
 template <int NW> DEV void ldw(uint32_t *w, const uint8_t *p)
 {
+#if LUTR_NT >= 2
+    typedef unsigned nt4 __attribute__((ext_vector_type(4)));
+    typedef unsigned nt2 __attribute__((ext_vector_type(2)));
+    if constexpr (NW == 4) { const nt4 v = __builtin_nontemporal_load((const nt4 *)p); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else if constexpr (NW == 2) { const nt2 v = __builtin_nontemporal_load((const nt2 *)p); w[0] = v.x; w[1] = v.y; }
+    else w[0] = __builtin_nontemporal_load((const uint32_t *)p);
+#else
     if constexpr (NW == 4) { const uint4 v = *(const uint4 *)p; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
     else if constexpr (NW == 2) { const uint2 v = *(const uint2 *)p; w[0] = v.x; w[1] = v.y; }
     else w[0] = *(const uint32_t *)p;
+#endif
 }
 template <int NW> DEV void stw(uint8_t *p, const uint32_t *w)
 {
+#if LUTR_NT
+    typedef unsigned nt4 __attribute__((ext_vector_type(4)));
+    typedef unsigned nt2 __attribute__((ext_vector_type(2)));
+    if constexpr (NW == 8) { __builtin_nontemporal_store(nt4{w[0], w[1], w[2], w[3]}, (nt4 *)p); __builtin_nontemporal_store(nt4{w[4], w[5], w[6], w[7]}, (nt4 *)(p + 16)); }
+    else if constexpr (NW == 4) __builtin_nontemporal_store(nt4{w[0], w[1], w[2], w[3]}, (nt4 *)p);
+    else if constexpr (NW == 2) __builtin_nontemporal_store(nt2{w[0], w[1]}, (nt2 *)p);
+    else __builtin_nontemporal_store(w[0], (uint32_t *)p);
+#else
     if constexpr (NW == 8) { *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]); *(uint4 *)(p + 16) = make_uint4(w[4], w[5], w[6], w[7]); }
     else if constexpr (NW == 4) *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]);
     else if constexpr (NW == 2) *(uint2 *)p = make_uint2(w[0], w[1]);
     else *(uint32_t *)p = w[0];
+#endif
 }
 
 template <int N> DEV void fence_words(uint32_t *w)
