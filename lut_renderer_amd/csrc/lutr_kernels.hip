@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void k_rgb_vec(LutConsts L, PlaneSet P, FrameG
         word_put<WIDE>(bo, i, o.b);
         word_put<WIDE>(ro, i, o.r);
     }
-    st_words<NW>(P.d[0] + fr * P.dfs[0] + y * P.ds[0] + xo, go);
-    st_words<NW>(P.d[1] + fr * P.dfs[1] + y * P.ds[1] + xo, bo);
-    st_words<NW>(P.d[2] + fr * P.dfs[2] + y * P.ds[2] + xo, ro);
+    st_words<NW, true>(P.d[0] + fr * P.dfs[0] + y * P.ds[0] + xo, go);
+    st_words<NW, true>(P.d[1] + fr * P.dfs[1] + y * P.ds[1] + xo, bo);
+    st_words<NW, true>(P.d[2] + fr * P.dfs[2] + y * P.ds[2] + xo, ro);
 }
 
 // WIN / WOUT: 16-bit containers in / out.  A 10-bit source written as 8 bit (the reference's libx264 default,
