@@ -1628,6 +1628,9 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     // (65^3: a tube that fits is 5 of ITS cells wide, +-20 8-bit codes -- 497 / 427 Gpx/s with it, 530 / 492 without: off above 40^3)
     if (!tg.whole && vv >= V_TAB && mode != LUTR_INTERP_NEAREST && (L.n1 <= 41 || getenv("LUTR_TUBE_H"))) {
         int h = (8 * (L.n1 - 2) + 16) / 32;                       // 8 at 33^3
+        // a short launch (under ~100 tiles per wave) does not earn back the ~8 us it takes to stage the widest tube: 5 cells there
+        // (UHD, 8 / 16 / 32 / 64 frames per launch, Gpx/s at H = 8 | 5: 351 | 369, 445 | 456, 533 | 541, 598 | 595)
+        if ((long long)G.nframes * tg.nsx * tg.nry < 100ll * max_waves) h = (5 * (L.n1 - 2) + 16) / 32;
         if (const char *e = getenv("LUTR_TUBE_H")) h = atoi(e);
         const float kappa = L.sc[0] * L.scale_f;
         const float eps = K.max_l * (1.0f / 2097152.0f) + 1e-3f;                 // as map_box
