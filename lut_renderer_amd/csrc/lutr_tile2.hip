@@ -338,16 +338,49 @@ DEV void ext_words(const uint32_t *w, uint32_t &mn, uint32_t &mx, bool first)
     }
 }
 
+// max only (the luma minimum is wanted by the window tests alone: tiles the tube takes never compute it)
+template <int WIN, int N>
+DEV void max_words(const uint32_t *w, uint32_t &mx, bool first)
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (first && k == 0) mx = w[0];
+        else mx = pk_max(mx, w[k]);
+        if constexpr (!WIN) mx = pk_max(mx, w[k] << 8);
+    }
+}
+template <int WIN, int N>
+DEV void min_words(const uint32_t *w, uint32_t &mn, bool first)
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (first && k == 0) mn = w[0];
+        else mn = pk_min(mn, w[k]);
+        if constexpr (!WIN) mn = pk_min(mn, w[k] << 8);
+    }
+}
+
+// everything but the luma minimum (luma_min below)
 template <int WIN, int WOUT, int CSX, int CSY>
 DEV Ext extremes(const TileIn<WIN, WOUT, CSX, CSY> &in)
 {
     using T = Tile<WIN, WOUT, CSX, CSY>;
     Ext e;
+    e.ymin = 0u;
 #pragma unroll
-    for (int dy = 0; dy < T::BH; dy++) ext_words<WIN, T::YWI>(in.y[dy], e.ymin, e.ymax, dy == 0);
+    for (int dy = 0; dy < T::BH; dy++) max_words<WIN, T::YWI>(in.y[dy], e.ymax, dy == 0);
     ext_words<WIN, T::CWI>(in.cb, e.cbmin, e.cbmax, true);
     ext_words<WIN, T::CWI>(in.cr, e.crmin, e.crmax, true);
     return e;
+}
+template <int WIN, int WOUT, int CSX, int CSY>
+DEV uint32_t luma_min(const TileIn<WIN, WOUT, CSX, CSY> &in)
+{
+    using T = Tile<WIN, WOUT, CSX, CSY>;
+    uint32_t mn = 0u;
+#pragma unroll
+    for (int dy = 0; dy < T::BH; dy++) min_words<WIN, T::YWI>(in.y[dy], mn, dy == 0);
+    return mn;
 }
 
 DEV uint32_t pk_subsat(uint32_t a, uint32_t b) { uint32_t o; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(o) : "v"(a), "v"(b)); return o; }
@@ -1367,7 +1400,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         fence_words<T::YWI * T::BH>(&in.y[0][0]); fence_words<T::CWI>(in.cb); fence_words<T::CWI>(in.cr);
         TK(tk_wait)                  // ... and this is the wait for this tile's own loads
 #endif
-        const Ext e = extremes<WIN, WOUT, CSX, CSY>(in);
+        Ext e = extremes<WIN, WOUT, CSX, CSY>(in);             // without the luma minimum: see below
         bool use_tube = false;
         if (TG.tube_h > 0) {
             // level 0: the tile's chroma keeps it inside the workgroup's grey tube (and its raw codes are legal for the clamp-free body)
@@ -1384,7 +1417,11 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
                 else use_tube = tube_holds<WIN, PRE>(K, TG, e);
             }
         }
-        bool use_lds = use_tube || box_holds(scratch_off, e);  // first level: raw extremes against the window's raw box
+        bool use_lds = use_tube;
+        if (!use_tube && !TG.whole) {
+            e.ymin = luma_min<WIN, WOUT, CSX, CSY>(in);
+            use_lds = box_holds(scratch_off, e);               // first level: raw extremes against the window's raw box
+        }
         if (LUTR_T2_EXP >= 1 && have_win) use_lds = true;
         TK(tk_head)
         st_tiles++;
