@@ -1405,14 +1405,16 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         if (TG.tube_h > 0) {
             // level 0: the tile's chroma keeps it inside the workgroup's grey tube (and its raw codes are legal for the clamp-free body)
             const uint32_t top = pack_hi<WIN>(TG.max_raw);
-            const bool legal = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
-            if (legal) {
-                const bool in_rect = __all((pk_subsat_sv(TG.tube_rlo, e.cbmin) | pk_subsat_vs(e.cbmax, TG.tube_rhi) |
-                                            pk_subsat_sv(TG.tube_rlo, e.crmin) | pk_subsat_vs(e.crmax, TG.tube_rhi)) == 0u);
-                if (in_rect) use_tube = true;
-                // per sample for the strict kernels (their tube is 6 cells wide: sigma = 16 frames +9 %, natural -0.8 %, 3 x chroma
-                // -1.5 %); the fast kernels' 8-cell tube gains 1.7 % there and loses 1.4 % on 3 x chroma: corner form
-                else if constexpr (T::NC <= 4 && V != V_FAST && LUTR_T2_TUBE_SAMPLES)
+            // one vote for the common case: chroma inside the raw interval (which lies inside the legal codes) and luma legal
+            const uint32_t ybits = pk_subsat_vs(e.ymax, top);
+            const uint32_t rbits = pk_subsat_sv(TG.tube_rlo, e.cbmin) | pk_subsat_vs(e.cbmax, TG.tube_rhi) |
+                                   pk_subsat_sv(TG.tube_rlo, e.crmin) | pk_subsat_vs(e.crmax, TG.tube_rhi);
+            if (__all((ybits | rbits) == 0u)) use_tube = true;
+            else if (__all((ybits | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u)) {
+                // legal, but outside the interval: the bound itself.  Per sample for the strict kernels (their tube is 6 cells wide:
+                // sigma = 16 frames +9 %, natural -0.8 %, 3 x chroma -1.5 %); the fast kernels' 8-cell tube gains 1.7 % there and loses
+                // 1.4 % on 3 x chroma: corner form
+                if constexpr (T::NC <= 4 && V != V_FAST && LUTR_T2_TUBE_SAMPLES)
                     use_tube = tube_holds_samples<WIN, WOUT, CSX, CSY, PRE>(K, TG, in);
                 else use_tube = tube_holds<WIN, PRE>(K, TG, e);
             }
