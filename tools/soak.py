@@ -41,6 +41,8 @@ def frame(rng, w, h, depth, csx, csy, full):
 
 
 def main():
+    import os
+    os.environ.setdefault("LUTR_SMALL_JOB_MPX", "0")          # "auto" must take the tile kernels whatever the launch size
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     eng = LutEngine(0)
     rng = np.random.default_rng(20261004)
@@ -53,6 +55,9 @@ def main():
         eng.set_lut(cube.CubeLut(n, scale, lat))
         fmt, depth, csx, csy = fmts[rng.integers(0, len(fmts))]
         w, h = int(rng.choice([512, 1024, 1920])), int(rng.choice([64, 136, 270]) * 2)
+        ragged = rng.random() < 0.25          # a width the 16-byte kernels cannot take whole: "auto" splits it, tile kernels + scalar rest
+        if ragged:
+            w -= 2 * int(rng.integers(1, 7))
         rg = str(rng.choice(["tv", "pc"]))
         kw = dict(pix_fmt=fmt, interp=str(rng.choice(["tetrahedral", "trilinear"])),
                   matrix_in=str(rng.choice(["bt709", "bt601", "bt2020nc"])), range_src=rg, range_in=rg)
@@ -60,26 +65,32 @@ def main():
             kw.update(range_src="pc", range_in="tv", lut_depth=8)
         src = frame(rng, w, h, depth, csx, csy, kw["range_in"] == "pc")
         dev = [torch.from_numpy(p.view(np.int16) if p.dtype == np.uint16 else p).to(eng.device).unsqueeze(0).repeat(4, 1, 1) for p in src]
-        eng.set_variant("vec_lds")
+        if rng.random() < 0.3:                # a row shard of the frames (FFmpeg's slice rule aligns to the chroma block)
+            r0 = 2 * int(rng.integers(0, h // 4)); kw.update(row0=r0, rows=2 * int(rng.integers(1, (h - r0) // 2 + 1)))
+        eng.set_variant("auto" if ragged else "vec_lds")
         eng.tile_stats(True)
         a = [t.clone() for t in eng.apply_yuv(dev, **kw)]
         st = eng.tile_stats(False)
         name = eng.last_kernel
         eng.set_variant("generic")
         b = eng.apply_yuv(dev, **kw)
+        r0, rn = kw.get("row0", 0), kw.get("rows", h)
+        rows_of = lambda i: slice(r0 >> (csy if i else 0), (r0 + rn) >> (csy if i else 0))     # only the shard's rows are written
+        a = [t[:, rows_of(i)] for i, t in enumerate(a)]
+        b = [t[:, rows_of(i)] for i, t in enumerate(b)]
         for i, (x, y) in enumerate(zip(a, b)):
             if not torch.equal(x, y):
                 d = (x.to(torch.int32) - y.to(torch.int32)).abs()
                 raise SystemExit(f"MISMATCH run {runs}: n={n} {fmt} {kw} {name} plane {i}: {int((d > 0).sum())} samples, max {int(d.max())}")
         # the fast kernels (their own, wider tube): at most one code from the strict result wherever they run
-        eng.set_variant("vec_lds")
+        eng.set_variant("auto" if ragged else "vec_lds")
         eng.set_precision("fast")
         c = eng.apply_yuv(dev, **kw)
         eng.set_precision("strict")
         if "fast" in eng.last_kernel:
             fast_runs += 1
             for i, (x, y) in enumerate(zip(c, b)):
-                d = (x.to(torch.int32) - y.to(torch.int32)).abs()
+                d = (x[:, rows_of(i)].to(torch.int32) - y.to(torch.int32)).abs()
                 # one code at the LUT's depth; behind the 8-bit prologue that is up to 4 codes of a 10-bit output
                 tol = 1 if kw.get("lut_depth", depth) == depth else 4
                 if int(d.max()) > tol:
