@@ -18,11 +18,17 @@ scaling (N x FRAMES frames, so per-GPU work is fixed); `strong` in the same line
 speed-up north_star words: the same FRAMES frames, rows split N ways.  The only collective is the RCCL
 broadcast of the lattice at LUT load, reported in `collective`.
 
-Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (6 B/px for
-yuv420p10le in+out, + the 431,244 B lattice) / the kernel's mean launch duration measured with HIP
-events on the launch stream.  `cpu_baseline` times the CPU oracle (kind "port": a restatement of FFmpeg
-lut3d, not FFmpeg) on the host cores.  `extra_Mpx_s` carries the same kernel on other frame statistics
-(sensor noise swept up to sigma = 64 codes, i.i.d. uniform) with the LDS-window hit / miss / gather counts.
+Rank 0 prints ONE JSON line.  `value`, `ms_per_step`, `roofline` and `dtype` describe the STRICT kernels
+(`config.precision`): fp32 lattice, fp32 blend in FFmpeg's scalar-C order, bit-identical to the oracle.  The
+tolerance-bounded FAST kernels (fp16 lattice, <= 1 code from strict) are timed on the same batch and reported
+in `other_precision` with their own `kernel_ms` and dtype string -- never as `value`.
+`roofline.achieved` = algorithmic bytes per launch (6 B/px for yuv420p10le in+out, + the 431,244 B lattice)
+/ the kernel's mean launch duration measured with HIP events on the launch stream.  `cpu_baseline` times the
+CPU oracle (kind "port": a restatement of FFmpeg lut3d, not FFmpeg) on the host cores.  `extra_Mpx_s` carries
+both precisions on other frame statistics (three times the chroma, sensor noise up to sigma = 64 codes,
+i.i.d. uniform) with the LDS-window hit / miss / gather counts.  `host_pipeline` is BASELINE config 5 (256 UHD
+full-range frames queued in pinned host memory, pc->tv prologue fused, overlapped hipMemcpyAsync) with the
+PCIe rates measured in the same run beside it; `host_us_per_apply` is the launcher's host cost per call.
 """
 from __future__ import annotations
 
@@ -42,6 +48,8 @@ sys.path.insert(0, str(ROOT))
 SIZES = {"1080p": (1920, 1080), "uhd": (3840, 2160), "8k": (7680, 4320)}
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 EXTRA_DISTS = ("vivid", "noise8", "noise16", "noise64", "uniform")
+# what the kernels of a precision compute in: `dtype` of the line is the arithmetic type, not a precision claim
+DTYPE = {"strict": "f32", "fast": "f32 coordinates and accumulation, f16 lattice"}
 
 
 def log(*a):
@@ -63,10 +71,11 @@ def parse_args(argv=None):
                     help="pc: full-range source -> the reference's prologue scale=in_range=pc:out_range=tv,format=<8-bit> "
                          "(ffmpeg.py:212-233, BASELINE config 5) runs fused ahead of the LUT")
     ap.add_argument("--interp", default="tetrahedral")
-    ap.add_argument("--precision", default="fast", choices=["strict", "fast"],
-                    help="fast (default, named in config.precision): the tolerance-bounded kernels, <= 1 code from strict at 8 "
-                         "and 10 bit (north_star allows 1 / 2 against FFmpeg; tests/test_fast_variant.py); strict: the "
-                         "bit-exact restatement of FFmpeg's scalar C.  The other one is timed too and reported beside `value`.")
+    ap.add_argument("--precision", default="strict", choices=["strict", "fast"],
+                    help="strict (default, named in config.precision): fp32 lattice and blend, the bit-exact restatement of "
+                         "FFmpeg's scalar C -- the reference's precision; fast: the tolerance-bounded kernels (fp16 lattice, "
+                         "<= 1 code from strict at 8 and 10 bit, tests/test_fast_variant.py).  The other one is timed too and "
+                         "reported in `other_precision`.")
     ap.add_argument("--lut", type=int, default=33, help="lattice size N of the generated log709 LUT")
     ap.add_argument("--dist", default="natural")
     ap.add_argument("--variant", default="auto")
@@ -84,11 +93,20 @@ def parse_args(argv=None):
                          "needs ~20 ms of load to leave its idle clock (DESIGN.md 5), whatever W the caller picks")
     ap.add_argument("--dither", default="none", choices=["none", "error_diffusion"],
                     help="also dither the final quantisation (reference option zscale_dither; YUV formats, informational)")
-    ap.add_argument("--pipeline", default="hbm", choices=["hbm", "host"],
-                    help="host: also time BASELINE config 5 (frames in pinned host memory, overlapped copies); "
-                         "reported as `host_pipeline`, never as `value`")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "hbm", "host"],
+                    help="auto (default): after the HBM-resident metric also time BASELINE config 5 -- 256 full-range frames "
+                         "in pinned host memory, pc->tv prologue + LUT, overlapped hipMemcpyAsync -- and the PCIe copy rates of "
+                         "this box beside it; reported as `host_pipeline`, never as `value`.  host: the same leg with the "
+                         "range / format options of this run instead of config 5's.  hbm: skip it")
     ap.add_argument("--host-frames", type=int, default=256)
-    return ap.parse_args(argv)
+    ap.add_argument("--no-host-cost", action="store_true", help="skip the host-microseconds-per-apply measurement")
+    ap.add_argument("--lean", action="store_true",
+                    help="the timed kernel(s) only: --no-cpu-baseline --no-extra --no-strong --pipeline hbm --no-host-cost (tools/)")
+    args = ap.parse_args(argv)
+    if args.lean:
+        args.no_cpu_baseline = args.no_extra = args.no_strong = args.no_host_cost = True
+        args.pipeline = "hbm"
+    return args
 
 
 # ---------------------------------------------------------------- self-launch (N > 1 without a launcher)
@@ -275,6 +293,133 @@ def cpu_baseline(lut, job, w, h, interp, dist_name, budget_s):
                       f"{el:.1f} s wall; CPU restatement of FFmpeg lut3d (no ffmpeg binary on this image)"}
 
 
+def pcie_rates(device, nbytes=256 << 20, reps=3):
+    """hipMemcpyAsync rates of THIS box, pinned host memory, GB/s: H2D alone, D2H alone, and both directions at once on two
+    streams (what the ring of `stream.HostPipeline` does).  The host pipeline's rate is judged against these, not a spec."""
+    import torch
+    hin, hout = torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    din, dout = torch.empty(nbytes, dtype=torch.uint8, device=device), torch.empty(nbytes, dtype=torch.uint8, device=device)
+    s1, s2 = torch.cuda.Stream(device), torch.cuda.Stream(device)
+
+    def run(h2d, d2h):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if h2d:
+                with torch.cuda.stream(s1):
+                    din.copy_(hin, non_blocking=True)
+            if d2h:
+                with torch.cuda.stream(s2):
+                    hout.copy_(dout, non_blocking=True)
+        s1.synchronize(); s2.synchronize()
+        return reps * nbytes / (time.perf_counter() - t0) / 1e9
+
+    run(True, True)
+    return {"h2d_alone": round(run(True, False), 1), "d2h_alone": round(run(False, True), 1),
+            "each_way_concurrent": round(run(True, True), 1), "copy_bytes": nbytes}
+
+
+def host_pipeline_leg(eng, args, job, pf, w, h, rank, world):
+    """BASELINE config 5: frames queued in pinned host memory, round-robin over the GPUs (whole frames per rank, every rank
+    drives its own 3-slot ring of 8-frame batches, H2D / kernel / D2H on separate HIP streams); total = all ranks' frames /
+    the slowest rank's time.  `auto` runs config 5 itself (full-range source, pc->tv prologue fused ahead of the LUT) whatever
+    the headline's range is; `host` keeps this run's options."""
+    import numpy as np
+    import torch
+    from lut_renderer_amd.stream import HostPipeline
+    if args.pipeline == "auto":
+        kw, full_range = dict(range_src="pc", range_in="tv", lut_depth=8), True
+    else:
+        kw = {k: v for k, v in job.kw.items() if k not in ("pix_fmt", "out_pix_fmt")}
+        full_range = args.range_src == "pc"
+    pipe = HostPipeline(eng, args.fmt, w, h, batch=8, slots=3, out_pix_fmt=args.out_fmt, interp=args.interp, **kw)
+    full = make_frames(pf, w, h, args.dist, 0, full_range)
+    one = b"".join(np.ascontiguousarray(p).tobytes() for p in full)
+    for sl in range(pipe.slots):                 # inputs pre-filled: the producer is not what is measured
+        pipe.host_in(sl)[:] = np.frombuffer(one * pipe.batch, dtype=np.uint8)
+    mine = args.host_frames // world + (1 if rank < args.host_frames % world else 0)
+    pipe.run(lambda b, m: m, lambda b, k: None, total_frames=24)        # warm-up
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    n_done = pipe.run(lambda b, m: m, lambda b, k: None, total_frames=mine)
+    torch.cuda.synchronize()
+    barrier(world)
+    el = time.perf_counter() - t0
+    kernel = eng.last_kernel
+    rates = pcie_rates(eng.device) if rank == 0 else None
+    (el,), (n_all,) = reduce_max_sum(eng, world, [el], [float(n_done)])
+    n_all = int(n_all)
+    gb = n_all * (pipe.fin.frame_bytes + pipe.fout.frame_bytes) / 1e9
+    each_way = gb / 2 / el
+    out = {"frames": n_all, "fps": round(n_all / el, 1), "Mpixels_s": round(n_all * w * h / el / 1e6, 1),
+           "pcie_GBps_each_way": round(each_way, 1), "gpus": world, "kernel": kernel,
+           "prologue": "scale=in_range=pc:out_range=tv,format=<8-bit> fused" if full_range else "none",
+           "note": "frames in pinned host memory, round-robin over the GPUs, per GPU a 3-slot ring of 8-frame batches with "
+                   "H2D / kernel / D2H on separate streams; pcie_GBps_each_way is the sum over GPUs"}
+    if rates:
+        out["pcie_measured_GBps"] = rates
+        out["frac_of_measured_pcie"] = round(each_way / world / rates["each_way_concurrent"], 3)
+    return out
+
+
+def host_us_per_apply(eng, job, args, n=1000):
+    """Host cost of one apply: `n` launches of ONE 1080p frame (same format / chain as the headline) issued back to back
+    without waiting.  `python` = wall per `LutEngine.apply_yuv` call (argument checks, ctypes, the C launcher);
+    `c_abi` = wall per bare `lutr_apply_yuv` call with prebuilt descriptors (the launcher alone); `gpu` = the launch's
+    duration on the device -- when it exceeds the host figure the queue, not the host, paces a stream of such calls."""
+    import ctypes as C
+    import torch
+    from lut_renderer_amd import _native
+    from lut_renderer_amd.engine import _planes_struct
+    pf = job.pf
+    w, h = 1920, 1080
+    src = build_batch(eng, pf, w, h, 1, args.dist, 1, args.range_src == "pc")
+    dst = alloc_out(eng, job, src, w, h)
+    out = {}
+    for variant in ("auto", "vec_lds"):
+        eng.set_variant(variant)
+        for _ in range(20):
+            job.apply(eng, src, dst, args.interp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            job.apply(eng, src, dst, args.interp)
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        # the same through the bare C-ABI: descriptors built once
+        s, _ = _planes_struct(src, eng.device)
+        d, _ = _planes_struct(dst, eng.device)
+        from lut_renderer_amd.engine import parse_pix_fmt
+        fin, fout = parse_pix_fmt(job.kw["pix_fmt"]), parse_pix_fmt(job.kw["out_pix_fmt"])
+        prm = _native.YuvParams()
+        prm.fmt_in, prm.fmt_out = fin.code, fout.code
+        prm.lut_depth = job.kw.get("lut_depth", fin.depth)
+        prm.matrix_in = prm.matrix_out = _native.MATRIX["bt709"]
+        prm.range_src = _native.RANGE[job.kw.get("range_src", "tv")]
+        prm.range_in = _native.RANGE[job.kw.get("range_in", job.kw.get("range_src", "tv"))]
+        prm.range_out = _native.RANGE["tv"]
+        lib, ctx, mode = eng._lib, eng._ctx, _native.INTERP[args.interp]
+        eng._bind_stream()
+        call = lib.lutr_apply_yuv
+        ps, pd, pp = C.byref(s), C.byref(d), C.byref(prm)
+        for _ in range(20):
+            _native.check(call(ctx, pp, mode, w, h, 1, ps, pd, 0, h))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            call(ctx, pp, mode, w, h, 1, ps, pd, 0, h)
+        t_c = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_c_all = time.perf_counter() - t0
+        out[variant] = {"kernel": eng.last_kernel, "python_us": round(t_issue / n * 1e6, 2), "c_abi_us": round(t_c / n * 1e6, 2),
+                        "gpu_us": round(min(t_all, t_c_all) / n * 1e6, 2)}
+    eng.set_variant(args.variant)
+    out["sample"] = f"{n} applies of one 1920x1080 {pf.name} frame, issued back to back on one stream"
+    return out
+
+
 def load_traffic(tag):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary, if one exists for this workload."""
     p = ROOT / "profiles" / "traffic.json"
@@ -354,8 +499,13 @@ def main():
     r0, r1 = my_rows(h, rank, world, align=align)
     nframes = args.frames * world                     # weak scaling: row block g of world x FRAMES full-height frames
     full_range = args.range_src == "pc"
+    t_setup = time.perf_counter()
     src = build_batch(eng, pf, w, h, nframes, args.dist, args.unique, full_range)
     dst = alloc_out(eng, job, src, w, h)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    if rank == 0:
+        log(f"[setup] {nframes} frames of {w}x{h} {args.fmt} in + out on every rank: {t_setup:.2f} s")
     px_rank = (r1 - r0) * w * nframes
 
     wall, kern = time_steps(eng, job, src, dst, args.interp, args.steps, args.warmup, world, r0, r1 - r0)
@@ -375,7 +525,8 @@ def main():
         oname = "strict" if args.precision == "fast" else "fast"
         eng.set_precision(oname)
         _, ok = time_steps(eng, job, src, dst, args.interp, max(5, args.steps // 4), 3, 1, r0, r1 - r0)
-        other = {"precision": oname, "Mpx_s": round(px_rank / ok / 1e6, 1), "kernel": eng.last_kernel,
+        other = {"precision": oname, "dtype": DTYPE[oname], "Mpx_s": round(px_rank / ok / 1e6, 1),
+                 "kernel_ms": round(ok * 1e3, 4), "kernel": eng.last_kernel,
                  "frac": round((bytes_per_px(pf) + bytes_per_px(pf_out)) * px_rank / ok / 1e9 / HBM_PEAK_GBPS, 4)}
         eng.set_precision(args.precision)
         if rank == 0:
@@ -402,48 +553,32 @@ def main():
             s2 = build_batch(eng, pf, w, h, nf_x, dname, args.unique, full_range)
             d2 = [t[:nf_x] for t in dst]
             for mode in modes:
-                _, k2 = time_steps(eng, job, s2, d2, mode, 8, 3, 1)
-                eng.tile_stats(True)
-                job.apply(eng, s2, d2, mode)
-                st = eng.tile_stats(False)
                 key = dname if len(modes) == 1 else f"{dname}/{mode}"
-                extra[key] = {"Mpx_s": round(nf_x * w * h / k2 / 1e6, 1), "kernel": eng.last_kernel,
-                              "tiles": st["tiles"], "tube_tiles": st["tube_tiles"], "level2_tiles": st["level2_tiles"],
-                              "window_misses": st["misses"], "gather_tiles": st["global_tiles"], "windows_staged": st["staged"]}
-                log(f"[extra] {key:22s} {extra[key]}")
+                extra[key] = {}
+                for prec in ("strict", "fast"):
+                    eng.set_precision(prec)
+                    _, k2 = time_steps(eng, job, s2, d2, mode, 8, 3, 1)
+                    eng.tile_stats(True)
+                    job.apply(eng, s2, d2, mode)
+                    st = eng.tile_stats(False)
+                    extra[key][prec] = {"Mpx_s": round(nf_x * w * h / k2 / 1e6, 1), "kernel": eng.last_kernel,
+                                        "tiles": st["tiles"], "tube_tiles": st["tube_tiles"], "level2_tiles": st["level2_tiles"],
+                                        "window_misses": st["misses"], "gather_tiles": st["global_tiles"],
+                                        "windows_staged": st["staged"]}
+                    log(f"[extra] {key:14s} {prec:6s} {extra[key][prec]}")
+                eng.set_precision(args.precision)
             del s2
 
     host_pipe = None
-    if args.pipeline == "host" and pf.family == "yuv":
-        # BASELINE config 5: frames queued in pinned host memory, round-robin over the GPUs (whole frames per rank,
-        # every rank drives its own 3-slot ring); total = all ranks' frames / the slowest rank's time
-        from lut_renderer_amd.stream import HostPipeline
-        kw = {k: v for k, v in job.kw.items() if k not in ("pix_fmt", "out_pix_fmt")}
-        pipe = HostPipeline(eng, args.fmt, w, h, batch=8, slots=3, out_pix_fmt=args.out_fmt, interp=args.interp, **kw)
-        full = make_frames(pf, w, h, args.dist, 0, full_range)
-        one = b"".join(np.ascontiguousarray(p).tobytes() for p in full)
-        for sl in range(pipe.slots):                 # inputs pre-filled: the producer is not what is measured
-            pipe.host_in(sl)[:] = np.frombuffer(one * pipe.batch, dtype=np.uint8)
-        mine = args.host_frames // world + (1 if rank < args.host_frames % world else 0)
-        pipe.run(lambda b, m: m, lambda b, k: None, total_frames=24)        # warm-up
-        torch.cuda.synchronize()
-        barrier(world)
-        t0 = time.perf_counter()
-        n_done = pipe.run(lambda b, m: m, lambda b, k: None, total_frames=mine)
-        torch.cuda.synchronize()
-        barrier(world)
-        el = time.perf_counter() - t0
-        (el,), (n_all,) = reduce_max_sum(eng, world, [el], [float(n_done)])
-        n_all = int(n_all)
-        gb = n_all * (pipe.fin.frame_bytes + pipe.fout.frame_bytes) / 1e9
-        host_pipe = {"frames": n_all, "fps": round(n_all / el, 1), "Mpixels_s": round(n_all * w * h / el / 1e6, 1),
-                     "pcie_GBps_each_way": round(gb / 2 / el, 1), "gpus": world, "kernel": eng.last_kernel,
-                     "prologue": "scale=in_range=pc:out_range=tv,format=<8-bit> fused" if full_range else "none",
-                     "note": "frames in pinned host memory, round-robin over the GPUs, per GPU a 3-slot ring of 8-frame "
-                             "batches with H2D / kernel / D2H on separate streams; PCIe Gen5 x16-bound (63 GB/s per "
-                             "direction and GPU by spec); pcie_GBps_each_way is the sum over GPUs"}
+    if args.pipeline != "hbm" and pf.family == "yuv" and args.dither == "none":
+        host_pipe = host_pipeline_leg(eng, args, job, pf, w, h, rank, world)
         if rank == 0:
             log(f"[host pipeline] {host_pipe}")
+
+    host_cost = None
+    if rank == 0 and world == 1 and pf.family == "yuv" and args.dither == "none" and not args.no_host_cost:
+        host_cost = host_us_per_apply(eng, job, args)
+        log(f"[host cost] {host_cost}")
 
     if rank == 0:
         bpp_in, bpp_out = bytes_per_px(pf), bytes_per_px(pf_out)
@@ -468,7 +603,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE[args.precision],
             "data": f"synthetic ({args.dist}: {args.unique} seeded frames tiled to the batch; generated log709 .cube)",
             "config": {
                 "workload": f"{w}x{h} {args.fmt}" + (f" -> {args.out_fmt}" if pf_out is not pf else "") +
@@ -479,7 +614,7 @@ def main():
                 "chain": chain, "precision": args.precision,
                 "distribution": args.dist, "kernel": kernel_name, "lds_window": tile_stats,
                 "dither": args.dither,
-                "parallelism": f"row-block x{world}", "bytes_per_pixel": bpp,
+                "parallelism": f"row-block x{world}", "bytes_per_pixel": bpp, "setup_s": round(t_setup, 2),
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -500,6 +635,8 @@ def main():
             result["extra_Mpx_s"] = extra
         if host_pipe:
             result["host_pipeline"] = host_pipe
+        if host_cost:
+            result["host_us_per_apply"] = host_cost
         if not args.no_cpu_baseline and world == 1 and pf.family != "packed":
             result["cpu_baseline"] = cpu_baseline(lut, job, w, h, args.interp, args.dist, args.cpu_seconds)
         elif world > 1:

@@ -193,6 +193,12 @@ int  lutr_ctx_lut_seal(lutr_ctx *ctx);
  * root's value-range seal.  Asynchronous: each context's later applies are ordered behind its copy.  This
  * is the single-process twin of the RCCL broadcast one-rank-per-GPU hosts do into lutr_ctx_lut_device. */
 int  lutr_lut_broadcast(lutr_ctx **ctxs, int nctx, int root);
+/* lutr_lut_broadcast with flags.  LUTR_BCAST_FORCE_PEER_COPY: take the cross-device call (hipMemcpyPeerAsync) also between
+ * two contexts of ONE GPU (a self-peer copy is legal) -- the test hook that lets a one-GPU box execute what an 8-GPU node
+ * runs.  The receiver's copy is recorded on its own event (a later lutr_ctx_set_stream waits for it) and the root waits
+ * for outstanding copies before its lattice is overwritten or freed. */
+enum { LUTR_BCAST_FORCE_PEER_COPY = 1 };
+int  lutr_lut_broadcast_ex(lutr_ctx **ctxs, int nctx, int root, unsigned flags);
 /* bytes of the device lattice layout for size n: (n+1)^3 nodes of 16 bytes */
 size_t lutr_lattice_bytes(int n);
 

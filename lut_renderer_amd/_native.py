@@ -21,6 +21,7 @@ RANGE = {"tv": 0, "pc": 1}
 DITHER = {"none": 0, "error_diffusion": 1}
 VARIANT = {"auto": 0, "generic": 1, "vec_global": 2, "vec_lds": 3}
 PRECISION = {"strict": 0, "fast": 1}
+BCAST_FORCE_PEER_COPY = 1
 
 #: every symbol include/lutr.h declares (tests check the library exports each one)
 SYMBOLS = (
@@ -28,7 +29,7 @@ SYMBOLS = (
     "lutr_cube_parse", "lutr_cube_free", "lutr_lut_parse", "lutr_lut_parse_ex", "lutr_ctx_set_prelut",
     "lutr_ctx_create", "lutr_ctx_destroy", "lutr_ctx_set_stream", "lutr_ctx_sync",
     "lutr_ctx_set_lut", "lutr_ctx_lut_alloc", "lutr_ctx_lut_device", "lutr_ctx_lut_seal",
-    "lutr_lattice_bytes", "lutr_lut_broadcast",
+    "lutr_lattice_bytes", "lutr_lut_broadcast", "lutr_lut_broadcast_ex",
     "lutr_apply_planar_rgb", "lutr_apply_packed_rgb", "lutr_apply_yuv", "lutr_apply_yuv_dither",
     "lutr_ctx_set_variant", "lutr_ctx_set_precision", "lutr_ctx_last_kernel", "lutr_ctx_tile_stats", "lutr_yuv_constants",
 )
@@ -111,6 +112,7 @@ def load() -> C.CDLL:
     lib.lutr_ctx_lut_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.lutr_ctx_lut_seal.argtypes = [vp]
     lib.lutr_lut_broadcast.argtypes = [C.POINTER(vp), ci, ci]
+    lib.lutr_lut_broadcast_ex.argtypes = [C.POINTER(vp), ci, ci, C.c_uint]
     lib.lutr_lattice_bytes.argtypes = [ci]
     lib.lutr_lattice_bytes.restype = C.c_size_t
     lib.lutr_apply_planar_rgb.argtypes = [vp, ci, ci, ci, ci, ci, C.POINTER(Planes), C.POINTER(Planes), ci, ci]

@@ -17,6 +17,7 @@ what ffmpeg's auto-inserted scaler emits ahead of an encoder.
 """
 from __future__ import annotations
 
+import threading
 from pathlib import Path
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -32,26 +33,31 @@ _lut_cache: Dict[Tuple[str, float, int], CubeLut] = {}
 # engines apply_lut creates for itself, kept per device tuple: a context holds a stream, the device lattice and the
 # kernels' work queue, and the reference calls the path once per task, not once per frame
 _engine_cache: Dict[Tuple[int, ...], object] = {}
+_cache_lock = threading.Lock()      # guards the two dictionaries; each engine carries its own lock for the calls on it
 
 
 def _cached_engine(devices: Tuple[int, ...]):
     from .engine import LutEngine
     from .multigpu import LutEngineGroup
-    eng = _engine_cache.get(devices)
-    if eng is None:
-        eng = LutEngine(devices[0]) if len(devices) == 1 else LutEngineGroup(devices)
-        _engine_cache[devices] = eng
-    return eng
+    with _cache_lock:
+        eng = _engine_cache.get(devices)
+        if eng is None:
+            eng = LutEngine(devices[0]) if len(devices) == 1 else LutEngineGroup(devices)
+            _engine_cache[devices] = eng
+        return eng
 
 
 def close_cached_engines() -> None:
     """Destroy the contexts `apply_lut` keeps between calls (also registered with atexit)."""
-    for eng in _engine_cache.values():
+    with _cache_lock:
+        engines = list(_engine_cache.values())
+        _engine_cache.clear()
+    for eng in engines:
         try:
-            eng.close()
+            with eng._lock:
+                eng.close()
         except Exception:
             pass
-    _engine_cache.clear()
 
 
 import atexit  # noqa: E402
@@ -61,10 +67,15 @@ atexit.register(close_cached_engines)
 def _cached_cube(path: Path) -> CubeLut:
     st = path.stat()
     key = (str(path), st.st_mtime, st.st_size)
-    if key not in _lut_cache:
-        _lut_cache.clear()
-        _lut_cache[key] = read_lut(path)
-    return _lut_cache[key]
+    with _cache_lock:
+        lut = _lut_cache.get(key)
+    if lut is None:
+        lut = read_lut(path)                   # parsed outside the lock: two tasks may parse two files at once
+        with _cache_lock:
+            if len(_lut_cache) >= 16:          # up to 16 concurrent tasks (task_manager.py:229-235), each with its own LUT
+                _lut_cache.clear()
+            lut = _lut_cache.setdefault(key, lut)
+    return lut
 
 
 def engine_call_for(plan: LutPlan, pix_fmt: str, out_pix_fmt: Optional[str] = None) -> dict:
@@ -93,7 +104,7 @@ def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: s
               height: Optional[int] = None, input_matrix: str = "auto", colorspace: Optional[str] = None,
               color_range: Optional[str] = None, output_tags: str = "bt709", out_pix_fmt: Optional[str] = None,
               zscale_dither: str = "none", out: Optional[Sequence] = None, engine=None,
-              devices: Sequence[int] = (0,)):
+              devices: Sequence[int] = (0,), precision: str = "strict"):
     """Apply `cube` to planar YUV frames on the GPU.  `planes` = (Y, Cb, Cr) torch tensors on the
     engine's device, each [H,W] or [F,H,W].  Returns (planes_out, tags) where `tags` is the colour
     metadata the reference would write for this policy (None = inherit / none).
@@ -102,7 +113,13 @@ def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: s
     None).  Otherwise `devices` names the GPUs: one device -> one context; several -> a LutEngineGroup that
     splits the rows of every frame over them inside this one process (lattice copied GPU to GPU, one launch
     per device, no host wait between launches).  Contexts made here are kept for the next call
-    (`close_cached_engines`)."""
+    (`close_cached_engines`) and are safe to share between the threads of a task pool: the engine's lock is held from
+    the lattice upload to the launch.
+
+    `precision` is an ENGINE setting, not one of the reference's (models.py:45-56 has no such field): "strict" (default)
+    is the bit-exact restatement of FFmpeg's scalar C in fp32; "fast" allows the tolerance-bounded kernels whose lattice
+    is fp16 (<= 1 code from strict at 8 and 10 bit) where they exist and silently runs strict elsewhere
+    (`engine.last_kernel` ends in `,fast` when they ran)."""
     devices = tuple(int(d) for d in devices)
     if not devices:
         raise ValueError("devices must name at least one GPU")
@@ -116,14 +133,20 @@ def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: s
     kw = engine_call_for(plan, pix_fmt, out_pix_fmt)
     # ffmpeg.py:305-307: any value other than "error_diffusion" leaves the chain without a dither filter
     kw["dither"] = "error_diffusion" if getattr(params, "zscale_dither", "none") == "error_diffusion" else "none"
+    if precision not in ("strict", "fast"):
+        raise ValueError(f"unknown precision '{precision}' (strict | fast)")
     own = engine is None
     eng = engine if engine is not None else _cached_engine(devices)
+    lut = None
     if cube is not None:
         lut = cube if isinstance(cube, CubeLut) else _cached_cube(Path(cube))
-        if getattr(eng, "_applied_lut", None) is not lut:        # same parsed LUT as last time: the device copy stands
-            eng.set_lut(lut)
+    with eng._lock:                 # upload, precision and launch of ONE task: no other thread's call gets in between
+        if lut is not None and eng._applied_lut is not lut:      # same parsed LUT as last time: the device copy stands
+            eng.set_lut(lut)                                     # (set_lut itself clears the marker)
             eng._applied_lut = lut
-    result = eng.apply_yuv(planes, out, **kw)
-    if own:
-        eng.sync()
+        if eng.precision != precision:
+            eng.set_precision(precision)
+        result = eng.apply_yuv(planes, out, **kw)
+        if own:
+            eng.sync()
     return result, output_color_tags(plan.output_policy)

@@ -28,6 +28,15 @@ def _hms(seconds: float) -> str:
     return f"{int(h):02d}:{int(m):02d}:{s:05.2f}"
 
 
+def _rate(text: str) -> float:
+    """'25', '29.97' or ffprobe's rational form '30000/1001'."""
+    num, _, den = str(text).partition("/")
+    value = float(num) / (float(den) if den else 1.0)
+    if not value > 0:
+        raise argparse.ArgumentTypeError(f"bad frame rate '{text}'")
+    return value
+
+
 def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="lut_renderer_amd.cli", description=__doc__.split("\n\n")[0])
     ap.add_argument("-i", "--input", required=True)
@@ -42,7 +51,10 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--zscale-dither", default="none", help="none | error_diffusion (models.py:46)")
     ap.add_argument("--colorspace", default=None)
     ap.add_argument("--color-range", default=None)
-    ap.add_argument("--fps", type=float, default=25.0)
+    ap.add_argument("--fps", type=_rate, default=25.0, help="frame rate, a number or a rational like 30000/1001")
+    ap.add_argument("--precision", default="strict", choices=["strict", "fast"],
+                    help="engine setting (not one of the reference's options): strict = bit-exact fp32 restatement of FFmpeg's "
+                         "scalar C (default); fast = tolerance-bounded kernels with an fp16 lattice, <= 1 code from strict")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("-y", action="store_true", help="overwrite the output (ffmpeg's -y)")
@@ -89,6 +101,7 @@ def main(argv=None) -> int:
         from .stream import HostPipeline
 
         eng = LutEngine(args.device)
+        eng.set_precision(args.precision)
         eng.set_lut(read_lut(args.cube))
         pix_fmt, out_fmt = kw.pop("pix_fmt"), kw.pop("out_pix_fmt")
         pipe = HostPipeline(eng, pix_fmt, w, h, batch=args.batch, out_pix_fmt=out_fmt, **kw)

@@ -250,14 +250,17 @@ def build_pipeline(task: Task, ffmpeg_bin: str = "ffmpeg") -> List[CommandStage]
 # ---------------------------------------------------------------- engine twin
 def engine_command(source: Path, output: Path, params: ProcessingParams, lut_path: Path,
                    source_info: VideoInfo, python_bin: Optional[str] = None, device: int = 0,
-                   notes: Optional[List[str]] = None) -> List[str]:
+                   notes: Optional[List[str]] = None, precision: str = "strict") -> List[str]:
     """`build_command`'s twin for the LUT stage alone: the argv of the ENGINE CLI (`python -m lut_renderer_amd.cli`)
     that applies exactly the chain `build_command` would put into `-vf` -- the same `LutPlan`, rendered as CLI options
     instead of as a filter string (ffmpeg.py:195-247, :287-310).  `source` / `output` are rawvideo files (or `-`) in
     `source_info.pix_fmt` and the pixel format `resolve_pix_fmt` picks; `task_manager.py:145-151` can Popen the result
     unchanged (same `Duration:` / `time=` / exit-code / SIGTERM contract).  `notes` receives the plan's notes, like
-    `build_command`'s out-parameter.  The copy guard of ffmpeg.py:255-256 applies: a LUT stage cannot be a stream copy."""
+    `build_command`'s out-parameter.  The copy guard of ffmpeg.py:255-256 applies: a LUT stage cannot be a stream copy.
+    `precision` is the engine's own setting (`--precision`, default strict; the reference's records have no such field)."""
     import sys as _sys
+    if precision not in ("strict", "fast"):
+        raise ValueError(f"unknown precision '{precision}' (strict | fast)")
     if lut_path is None:
         raise ValueError("engine_command renders the LUT stage: lut_path is required")
     if source_info is None or not source_info.pix_fmt or not source_info.width or not source_info.height:
@@ -285,7 +288,23 @@ def engine_command(source: Path, output: Path, params: ProcessingParams, lut_pat
     if source_info.color_range:
         cmd += ["--color-range", str(source_info.color_range)]
     if source_info.fps:
-        cmd += ["--fps", f"{float(source_info.fps):g}"]
+        cmd += ["--fps", fps_rational(source_info.fps)]
     if device:
         cmd += ["--device", str(int(device))]
+    if precision != "strict":
+        cmd += ["--precision", precision]
     return cmd
+
+
+def fps_rational(fps) -> str:
+    """A frame rate as the rational ffprobe reported (`r_frame_rate`): `VideoInfo.fps` is that fraction parsed to a float
+    (media_info.py:135-137), and printing it with six digits (29.97) makes timestamps drift against the source.  NTSC rates
+    come back as N000/1001, everything else as the closest fraction with a denominator up to 1001."""
+    from fractions import Fraction
+    value = float(fps)
+    for den in (1, 1001):
+        num = round(value * den)
+        if num > 0 and abs(num / den - value) <= 1e-6 * value:
+            return str(num) if den == 1 else f"{num}/{den}"
+    frac = Fraction(value).limit_denominator(1001)
+    return str(frac.numerator) if frac.denominator == 1 else f"{frac.numerator}/{frac.denominator}"

@@ -212,9 +212,7 @@ int read_csp(Lines &in, const char *path, std::vector<float> &tab, int &n, float
             for (long j = 0; j < npoints; j++) {
                 if (!next_float(in, v) || !finite_bits(v)) return fail(LUTR_EILSEQ, path, "invalid data");
                 omin[c] = std::min(omin[c], v); omax[c] = std::max(omax[c], v);
-                pout[c][(size_t)j] = v;
-                if (j > 0 && v < last) return fail(LUTR_EILSEQ, path, "invalid file has non-monotonic pre-lut");
-                last = v;
+                pout[c][(size_t)j] = v;          // outputs: range only -- lut3d checks monotonicity on the INPUT points alone
             }
         } else if (npoints == 2) {
             if (!in.record() || std::sscanf(in.buf, "%f %f", &imin[c], &imax[c]) != 2) return fail(LUTR_EILSEQ, path, "invalid data");

@@ -185,7 +185,22 @@ struct lutr_ctx {
     int pre_size = 0;
     float pre_min[3] = {0, 0, 0}, pre_scale[3] = {0, 0, 0};
     float *pre_dev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // lutr_lut_broadcast: copies other contexts are still reading out of THIS context's lattice (one event per receiver,
+    // recorded on the receiver's stream behind its copy).  The lattice must not be overwritten or freed before they finish.
+    std::vector<std::pair<int, hipEvent_t>> readers;      // (receiver's device, event)
 };
+
+// Wait for every peer copy that reads this context's lattice, then forget the events.
+static void wait_readers(lutr_ctx *c)
+{
+    for (auto &r : c->readers) {
+        (void)hipEventSynchronize(r.second);
+        (void)hipSetDevice(r.first);
+        (void)hipEventDestroy(r.second);
+    }
+    if (!c->readers.empty()) (void)hipSetDevice(c->device);
+    c->readers.clear();
+}
 
 static void drop_lat16(lutr_ctx *c)
 {
@@ -271,6 +286,7 @@ int lutr_ctx_create(int device, lutr_ctx **out)
 void lutr_ctx_destroy(lutr_ctx *c)
 {
     if (!c) return;
+    wait_readers(c);
     (void)hipSetDevice(c->device);
     drop_lat16(c);
     drop_prelut_tables(c);
@@ -374,6 +390,7 @@ static int alloc_lattice(lutr_ctx *c, int n, const float scale[3])
             return LUTR_EINVAL;
         }
     HIP_TRY(hipSetDevice(c->device));
+    wait_readers(c);                 // peers of an earlier lutr_lut_broadcast may still be copying out of the buffer
     drop_lat16(c);                   // they describe the previous lattice
     drop_prelut_tables(c);           // and so does a prelut: it belongs to the LUT file (set it again after the lattice)
     c->prelut.clear(); c->pre_size = 0;
@@ -511,9 +528,14 @@ int lutr_ctx_lut_seal(lutr_ctx *c)
     return LUTR_OK;
 }
 
-int lutr_lut_broadcast(lutr_ctx **ctxs, int nctx, int root)
+int lutr_lut_broadcast(lutr_ctx **ctxs, int nctx, int root) { return lutr_lut_broadcast_ex(ctxs, nctx, root, 0); }
+
+int lutr_lut_broadcast_ex(lutr_ctx **ctxs, int nctx, int root, unsigned flags)
 {
-    if (!ctxs || nctx < 1 || root < 0 || root >= nctx) { set_error("lutr_lut_broadcast: bad arguments"); return LUTR_EINVAL; }
+    if (!ctxs || nctx < 1 || root < 0 || root >= nctx || (flags & ~(unsigned)LUTR_BCAST_FORCE_PEER_COPY)) {
+        set_error("lutr_lut_broadcast: bad arguments");
+        return LUTR_EINVAL;
+    }
     for (int i = 0; i < nctx; i++)
         if (!ctxs[i]) { set_error("lutr_lut_broadcast: null context %d", i); return LUTR_EINVAL; }
     lutr_ctx *r = ctxs[root];
@@ -528,12 +550,23 @@ int lutr_lut_broadcast(lutr_ctx **ctxs, int nctx, int root)
         int rc = alloc_lattice(c, r->n, r->scale);        // selects c's device
         if (rc) return rc;
         HIP_TRY(hipStreamWaitEvent(c->stream, r->done, 0));
-        if (c->device == r->device)
+        // (LUTR_BCAST_FORCE_PEER_COPY: the cross-device call on a same-device pair -- a self-peer copy is legal -- so that a
+        // one-GPU box executes the branch an 8-GPU node takes)
+        if (c->device == r->device && !(flags & LUTR_BCAST_FORCE_PEER_COPY))
             HIP_TRY(hipMemcpyAsync(c->lat, r->lat, r->lat_bytes, hipMemcpyDeviceToDevice, c->stream));
         else
             HIP_TRY(hipMemcpyPeerAsync(c->lat, c->device, r->lat, r->device, r->lat_bytes, c->stream));   // xGMI, GPU to GPU
         c->unit = r->unit;           // same nodes: the root's scan of the value range holds for the copy
+        // later applies of the receiver are ordered behind its copy even if it is rebound to another stream first
+        HIP_TRY(hipEventRecord(c->done, c->stream));
+        c->pending = true;
+        // ... and the root must not overwrite or free the buffer while this copy reads it
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, c->stream));
+        r->readers.emplace_back(c->device, ev);
     }
+    HIP_TRY(hipSetDevice(r->device));
     return LUTR_OK;
 }
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import re
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -129,6 +130,13 @@ class LutEngine:
         self.n = 0
         self.scale = None
         self.use_torch_stream = use_torch_stream
+        # One context = one stream, one lattice, one work queue (include/lutr.h: thread-safe per context, contexts are not
+        # shared between threads).  The reference runs up to 16 tasks on a thread pool (task_manager.py:229-235) and ctypes
+        # releases the GIL, so every call that touches the context takes this lock; `api.apply_lut` holds it across
+        # set_lut + apply so that a cached engine cannot render one task with another task's lattice.
+        self._lock = threading.RLock()
+        self.precision = "strict"
+        self._applied_lut = None          # the CubeLut object apply_lut uploaded last (its upload-skipping shortcut)
 
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
@@ -152,10 +160,12 @@ class LutEngine:
     def set_lut(self, lut: CubeLut) -> None:
         table = np.ascontiguousarray(lut.table, dtype=np.float32)
         scale = (C.c_float * 3)(*[float(v) for v in lut.scale])
-        _native.check(self._lib.lutr_ctx_set_lut(
-            self._ctx, table.ctypes.data_as(C.POINTER(C.c_float)), int(lut.n), scale))
-        self.n, self.scale = int(lut.n), np.array(lut.scale, dtype=np.float32)
-        self.set_prelut(getattr(lut, "prelut", None))
+        with self._lock:
+            self._applied_lut = None      # any direct upload invalidates apply_lut's "same LUT as last time" shortcut
+            _native.check(self._lib.lutr_ctx_set_lut(
+                self._ctx, table.ctypes.data_as(C.POINTER(C.c_float)), int(lut.n), scale))
+            self.n, self.scale = int(lut.n), np.array(lut.scale, dtype=np.float32)
+            self.set_prelut(getattr(lut, "prelut", None))
 
     def set_prelut(self, pre) -> None:
         """lut3d's prelut (a cineSpace shaper, `cube.Prelut`) for the lattice just set, or None to remove it.  Uploading a
@@ -184,6 +194,7 @@ class LutEngine:
         """Rank `src` uploads the lattice; every other rank receives it with ONE broadcast
         (RCCL over xGMI on GPUs).  No other collective exists on this path."""
         import torch.distributed as dist
+        self._applied_lut = None
         rank = dist.get_rank(group)
         meta = torch.zeros(4, dtype=torch.float32, device=self.device)
         if rank == src:
@@ -226,7 +237,11 @@ class LutEngine:
     def set_precision(self, name: str) -> None:
         """"strict" (default): bit-exact with FFmpeg's scalar C.  "fast": allow the tolerance-bounded tile kernels
         (<= 1 code from strict at 8 and 10 bit; include/lutr.h lutr_ctx_set_precision)."""
-        _native.check(self._lib.lutr_ctx_set_precision(self._ctx, _native.PRECISION[name]))
+        if name not in _native.PRECISION:
+            raise ValueError(f"unknown precision '{name}' (strict | fast)")
+        with self._lock:
+            _native.check(self._lib.lutr_ctx_set_precision(self._ctx, _native.PRECISION[name]))
+            self.precision = name
 
     @property
     def last_kernel(self) -> str:
@@ -264,9 +279,10 @@ class LutEngine:
         if nf != nfd:
             raise ValueError("src and dst disagree on the number of frames")
         rows = h - row0 if rows is None else rows
-        self._bind_stream()
-        _native.check(self._lib.lutr_apply_planar_rgb(
-            self._ctx, depth, _native.INTERP[interp], w, h, nf, C.byref(s), C.byref(d), row0, rows))
+        with self._lock:
+            self._bind_stream()
+            _native.check(self._lib.lutr_apply_planar_rgb(
+                self._ctx, depth, _native.INTERP[interp], w, h, nf, C.byref(s), C.byref(d), row0, rows))
         return dst
 
     def apply_packed(self, src: torch.Tensor, dst: Optional[torch.Tensor] = None, *, pix_fmt: str,
@@ -297,10 +313,11 @@ class LutEngine:
         h, w = src.shape[-3], src.shape[-2]
         nf = src.shape[0] if src.dim() == 4 else 1
         rows = h - row0 if rows is None else rows
-        self._bind_stream()
-        _native.check(self._lib.lutr_apply_packed_rgb(
-            self._ctx, _native.packed_code(bits, nc, ro, go, bo), _native.INTERP[interp], w, h, nf,
-            C.byref(descs[0]), C.byref(descs[1]), row0, rows))
+        with self._lock:
+            self._bind_stream()
+            _native.check(self._lib.lutr_apply_packed_rgb(
+                self._ctx, _native.packed_code(bits, nc, ro, go, bo), _native.INTERP[interp], w, h, nf,
+                C.byref(descs[0]), C.byref(descs[1]), row0, rows))
         return dst
 
     def apply_yuv(self, src: Sequence[torch.Tensor], dst: Optional[Sequence[torch.Tensor]] = None, *,
@@ -336,15 +353,16 @@ class LutEngine:
         if nf != nfd:
             raise ValueError("src and dst disagree on the number of frames")
         rows = h - row0 if rows is None else rows
-        self._bind_stream()
-        if dither != "none":
-            if row0 != 0 or rows != h:
-                raise ValueError("error-diffusion dither couples the rows of a frame: whole frames only")
-            _native.check(self._lib.lutr_apply_yuv_dither(
-                self._ctx, C.byref(p), _native.INTERP[interp], _native.DITHER[dither], w, h, nf, C.byref(s), C.byref(d)))
-            return dst
-        _native.check(self._lib.lutr_apply_yuv(
-            self._ctx, C.byref(p), _native.INTERP[interp], w, h, nf, C.byref(s), C.byref(d), row0, rows))
+        if dither != "none" and (row0 != 0 or rows != h):
+            raise ValueError("error-diffusion dither couples the rows of a frame: whole frames only")
+        with self._lock:
+            self._bind_stream()
+            if dither != "none":
+                _native.check(self._lib.lutr_apply_yuv_dither(
+                    self._ctx, C.byref(p), _native.INTERP[interp], _native.DITHER[dither], w, h, nf, C.byref(s), C.byref(d)))
+            else:
+                _native.check(self._lib.lutr_apply_yuv(
+                    self._ctx, C.byref(p), _native.INTERP[interp], w, h, nf, C.byref(s), C.byref(d), row0, rows))
         return dst
 
 

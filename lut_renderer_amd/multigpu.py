@@ -19,6 +19,8 @@ scale a batch job; this class exists so that the untouched caller of the referen
 from __future__ import annotations
 
 import ctypes as C
+import os
+import threading
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -33,10 +35,19 @@ from .shard import row_blocks
 class LutEngineGroup:
     """Contexts on `devices` (repeats allowed: two contexts on one GPU split its frames in two launches)."""
 
-    def __init__(self, devices: Sequence[int]):
+    def __init__(self, devices: Sequence[int], treat_as_remote: Optional[bool] = None):
         if not devices:
             raise ValueError("at least one device")
         self.devices = tuple(int(d) for d in devices)
+        # Test hook for boxes with one GPU: every engine after the first behaves as if it sat on ANOTHER device -- its row
+        # block is sliced, copied (a same-device `.to(copy=True)` stands in for the peer copy), applied as a short frame of its
+        # own and copied back, and `lutr_lut_broadcast` takes its hipMemcpyPeerAsync branch (a self-peer copy is legal).
+        # LUTR_GROUP_FORCE_REMOTE=1 sets it from the environment.  Never set in production.
+        self.treat_as_remote = bool(int(os.environ.get("LUTR_GROUP_FORCE_REMOTE", "0"))) if treat_as_remote is None \
+            else bool(treat_as_remote)
+        self._lock = threading.RLock()
+        self._applied_lut = None
+        self.precision = "strict"
         self.engines: List[LutEngine] = []
         try:
             for d in self.devices:
@@ -65,16 +76,20 @@ class LutEngineGroup:
     # -- lattice ----------------------------------------------------------
     def set_lut(self, lut: CubeLut) -> None:
         """Upload on the first device, then ONE broadcast call: every other context receives the lattice GPU to GPU."""
-        root = self.engines[0]
-        root.set_lut(lut)
-        if len(self.engines) > 1:
-            for e in self.engines:
-                e._bind_stream()
-            arr = (C.c_void_p * len(self.engines))(*[e._ctx for e in self.engines])
-            _native.check(self._lib.lutr_lut_broadcast(arr, len(self.engines), 0))
-            for e in self.engines[1:]:
-                e.n, e.scale = root.n, np.array(root.scale, dtype=np.float32)
-                e.set_prelut(getattr(lut, "prelut", None))         # host-side state: it does not travel with the lattice copy
+        with self._lock:
+            self._applied_lut = None
+            root = self.engines[0]
+            root.set_lut(lut)
+            if len(self.engines) > 1:
+                for e in self.engines:
+                    e._bind_stream()
+                arr = (C.c_void_p * len(self.engines))(*[e._ctx for e in self.engines])
+                flags = _native.BCAST_FORCE_PEER_COPY if self.treat_as_remote else 0
+                _native.check(self._lib.lutr_lut_broadcast_ex(arr, len(self.engines), 0, flags))
+                for e in self.engines[1:]:
+                    e._applied_lut = None
+                    e.n, e.scale = root.n, np.array(root.scale, dtype=np.float32)
+                    e.set_prelut(getattr(lut, "prelut", None))     # host-side state: it does not travel with the lattice copy
 
     def load_cube(self, path) -> CubeLut:
         lut = read_lut(path)
@@ -88,6 +103,7 @@ class LutEngineGroup:
     def set_precision(self, name: str) -> None:
         for e in self.engines:
             e.set_precision(name)
+        self.precision = name
 
     @property
     def last_kernels(self) -> List[str]:
@@ -100,6 +116,11 @@ class LutEngineGroup:
     # -- apply ------------------------------------------------------------
     def apply_yuv(self, src: Sequence[torch.Tensor], dst: Optional[Sequence[torch.Tensor]] = None, *, pix_fmt: str,
                   out_pix_fmt: Optional[str] = None, **kw):
+        with self._lock:
+            return self._apply_yuv(src, dst, pix_fmt=pix_fmt, out_pix_fmt=out_pix_fmt, **kw)
+
+    def _apply_yuv(self, src: Sequence[torch.Tensor], dst: Optional[Sequence[torch.Tensor]] = None, *, pix_fmt: str,
+                   out_pix_fmt: Optional[str] = None, **kw):
         """`LutEngine.apply_yuv` with the rows of every frame split over the group's devices.
         `src` planes live on one device (any); `dst`, if given, on the same one."""
         if kw.get("dither", "none") != "none":
@@ -117,10 +138,11 @@ class LutEngineGroup:
         blocks = row_blocks(h, len(self.engines), align=bh)
         self.last_blocks = blocks
         pending = []
-        for eng, (r0, r1) in zip(self.engines, blocks):
+        self.last_remote = 0                                       # row blocks that took the copy-there-and-back path
+        for k, (eng, (r0, r1)) in enumerate(zip(self.engines, blocks)):
             if r1 <= r0:
                 continue
-            if eng.device == home:
+            if eng.device == home and not (self.treat_as_remote and k > 0):
                 # same GPU: launch on the caller's planes, rows [r0, r1)
                 eng.apply_yuv(src, dst, pix_fmt=pix_fmt, out_pix_fmt=out_pix_fmt, row0=r0, rows=r1 - r0, **kw)
                 continue
@@ -128,8 +150,10 @@ class LutEngineGroup:
             c0, c1 = r0 >> fin.csy, (r1 + bh - 1) >> fin.csy
             rng = [(r0, r1), (c0, c1), (c0, c1)]
             with torch.cuda.device(eng.device):
-                part = [p[..., a:b, :].to(eng.device, non_blocking=True) for p, (a, b) in zip(src, rng)]
+                part = [p[..., a:b, :].to(eng.device, non_blocking=True, copy=True).contiguous()
+                        for p, (a, b) in zip(src, rng)]
                 out = eng.apply_yuv(part, None, pix_fmt=pix_fmt, out_pix_fmt=out_pix_fmt, **kw)
+            self.last_remote += 1
             pending.append((out, rng))
         for out, rng in pending:                                   # copies back: queued after every launch was issued
             for d, o, (a, b) in zip(dst, out, rng):

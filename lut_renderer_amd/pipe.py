@@ -6,7 +6,12 @@ The reference runs ONE ffmpeg process per stage whose filtergraph does decode, `
 
     ffmpeg -i SRC -f rawvideo -pix_fmt <src fmt> pipe:1          (decoder: the reference's input options, no filters)
       | python -m lut_renderer_amd.cli -i - -o - ...               (engine: `command.engine_command`, the same LutPlan)
-      | ffmpeg -f rawvideo -pix_fmt <out fmt> -s WxH -r FPS -i pipe:0 <the reference's codec / rate / tag options> OUT
+      | ffmpeg -f rawvideo -pix_fmt <out fmt> -s WxH -r NUM/DEN -i pipe:0 -i SRC -map 0:v:0 -map 1:a? -map 1:s?
+               -map_metadata 1 -map_chapters 1 <the reference's codec / rate / tag options> OUT
+
+The encoder reads the source a second time for everything that is not video: the reference's single ffmpeg process carries the
+source's audio (its `-c:a copy` / aac options), subtitles, chapters and container metadata into the output, and a raw pipe has
+none of them.  The frame rate travels as the rational ffprobe reported (30000/1001, not 29.97).
 
 `engine_stage_commands` derives all three argv lists from the arguments `build_command` takes; the encoder's options are what
 `build_command` itself emits once the `-vf` chain is taken out (the engine has already applied it, including `format=`).
@@ -26,7 +31,7 @@ from dataclasses import dataclass
 from pathlib import Path
 from typing import List, Optional
 
-from .command import build_command, engine_command
+from .command import build_command, engine_command, fps_rational
 from .params import ProcessingParams, VideoInfo
 from .plan import resolve_pix_fmt
 
@@ -40,11 +45,13 @@ class StageCommands:
 
 
 def engine_stage_commands(source: Path, output: Path, params: ProcessingParams, lut_path: Path, source_info: VideoInfo,
-                          ffmpeg_bin: str = "ffmpeg", python_bin: Optional[str] = None, device: int = 0) -> StageCommands:
+                          ffmpeg_bin: str = "ffmpeg", python_bin: Optional[str] = None, device: int = 0,
+                          precision: str = "strict") -> StageCommands:
     """The three argv lists of one LUT stage.  Raises what `build_command` / `engine_command` raise (copy guard, missing
     geometry)."""
     notes: List[str] = []
-    engine = engine_command(Path("-"), Path("-"), params, lut_path, source_info, python_bin=python_bin, device=device, notes=notes)
+    engine = engine_command(Path("-"), Path("-"), params, lut_path, source_info, python_bin=python_bin, device=device, notes=notes,
+                            precision=precision)
     if source_info.duration:
         engine += ["--duration", f"{float(source_info.duration):.3f}"]
     decoder = [ffmpeg_bin, "-hide_banner", "-nostdin", "-i", str(source), "-map", "0:v:0", "-f", "rawvideo",
@@ -57,12 +64,15 @@ def engine_stage_commands(source: Path, output: Path, params: ProcessingParams, 
             out_fmt = engine[engine.index("--out-pix-fmt") + 1]
     raw_in = ["-f", "rawvideo", "-pix_fmt", out_fmt, "-s", f"{source_info.width}x{source_info.height}"]
     if source_info.fps:
-        raw_in += ["-r", f"{float(source_info.fps):g}"]
+        raw_in += ["-r", fps_rational(source_info.fps)]
     enc_notes: List[str] = []
     tail = build_command(Path("pipe:0"), output, params, lut_path=None, ffmpeg_bin=ffmpeg_bin, source_info=source_info,
                          notes=enc_notes)
     i = tail.index("-i")
-    encoder = tail[:i] + raw_in + tail[i:]
+    # input 0 = the engine's frames, input 1 = the source again for audio / subtitles / chapters / metadata (`?`: optional
+    # streams; video is taken from the pipe only, so the source's picture is never decoded a second time)
+    side = ["-i", str(source), "-map", "0:v:0", "-map", "1:a?", "-map", "1:s?", "-map_metadata", "1", "-map_chapters", "1"]
+    encoder = tail[:i] + raw_in + tail[i:i + 2] + side + tail[i + 2:]
     # colour tags are decided by the LUT policy (ffmpeg.py:348-383), which build_command only applies with a lut_path:
     # take them from the full command
     full = build_command(source, output, params, lut_path=lut_path, ffmpeg_bin=ffmpeg_bin, source_info=source_info, notes=[])
@@ -119,11 +129,13 @@ def main(argv=None) -> int:
     ap.add_argument("--info", required=True, help="VideoInfo fields as JSON: width, height, pix_fmt, fps, colorspace, ...")
     ap.add_argument("--ffmpeg", default="ffmpeg")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--precision", default="strict", choices=["strict", "fast"], help="engine setting, see lut_renderer_amd.cli")
     a = ap.parse_args(argv)
     try:
         params = ProcessingParams.from_dict(json.loads(a.params))
         info = VideoInfo(**json.loads(a.info))
-        cmds = engine_stage_commands(Path(a.input), Path(a.output), params, Path(a.cube), info, ffmpeg_bin=a.ffmpeg, device=a.device)
+        cmds = engine_stage_commands(Path(a.input), Path(a.output), params, Path(a.cube), info, ffmpeg_bin=a.ffmpeg, device=a.device,
+                                     precision=a.precision)
     except Exception as exc:
         print(f"Error: {exc}", flush=True)
         return 1

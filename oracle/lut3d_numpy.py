@@ -130,18 +130,19 @@ def apply_rgb(table, scale, depth, mode, planes):
     return [go.astype(dt), bo.astype(dt), ro.astype(dt)]
 
 
-def apply_yuv(table, scale, mode, k, din, dl, dout, csx, csy, planes):
-    """k: oracle.binding.YuvConsts (constants are shared data, the pixel math is separate)."""
+def _clip_floor(v, hi):
+    return np.clip(np.floor(v), F(0), F(hi)).astype(F)
+
+
+def yuv_to_rgb_codes(k, csx, csy, planes):
+    """Stage 1 of the YUV contract: optional range/depth prologue, then YUV -> integer RGB at the LUT depth --
+    what FFmpeg hands lut3d.  Returns (R, G, B) as int64 arrays at luma resolution."""
     y, cb, cr = [p.astype(F) for p in planes]
     h, w = y.shape
-
-    def clip_floor(v, hi):
-        return np.clip(np.floor(v), F(0), F(hi)).astype(F)
-
     if k.pre:
-        y = clip_floor(_fma(F(k.py), y, F(k.pyb)), k.pre_max)
-        cb = clip_floor(_fma(F(k.pc), cb, F(k.pcb)), k.pre_max)
-        cr = clip_floor(_fma(F(k.pc), cr, F(k.pcb)), k.pre_max)
+        y = _clip_floor(_fma(F(k.py), y, F(k.pyb)), k.pre_max)
+        cb = _clip_floor(_fma(F(k.pc), cb, F(k.pcb)), k.pre_max)
+        cr = _clip_floor(_fma(F(k.pc), cr, F(k.pcb)), k.pre_max)
     cbd = (cb - F(k.coff)).astype(F)
     crd = (cr - F(k.coff)).astype(F)
     rv = (F(k.krv) * crd).astype(F)
@@ -152,21 +153,32 @@ def apply_yuv(table, scale, mode, k, din, dl, dout, csx, csy, planes):
         return np.repeat(np.repeat(a, 1 << csy, axis=0), 1 << csx, axis=1)[:h, :w]
 
     yy = _fma(F(k.ky), y, F(k.yb))
-    rq = clip_floor((yy + up(rv)).astype(F), k.max_l)
-    gq = clip_floor((yy + up(gv)).astype(F), k.max_l)
-    bq = clip_floor((yy + up(bu)).astype(F), k.max_l)
-    ro, go, bo = [a.astype(F) for a in lut3d_codes(table, scale, dl, mode, rq.astype(np.int64),
-                                                   gq.astype(np.int64), bq.astype(np.int64))]
-    yo = clip_floor(_fma(F(k.cyr), ro, _fma(F(k.cyg), go, _fma(F(k.cyb), bo, F(k.yob)))), k.max_o)
+    rq = _clip_floor((yy + up(rv)).astype(F), k.max_l)
+    gq = _clip_floor((yy + up(gv)).astype(F), k.max_l)
+    bq = _clip_floor((yy + up(bu)).astype(F), k.max_l)
+    return rq.astype(np.int64), gq.astype(np.int64), bq.astype(np.int64)
+
+
+def rgb_codes_to_yuv(k, dout, csx, csy, rgb):
+    """Stage 3: integer RGB (lut3d's output) -> YUV at the output depth, chroma = block mean (1/n folded into the constants)."""
+    ro, go, bo = [np.asarray(a).astype(F) for a in rgb]
+    h, w = ro.shape
+    yo = _clip_floor(_fma(F(k.cyr), ro, _fma(F(k.cyg), go, _fma(F(k.cyb), bo, F(k.yob)))), k.max_o)
     bh, bw = 1 << csy, 1 << csx
-    ch, cw = cb.shape
+    ch, cw = (h + bh - 1) >> csy, (w + bw - 1) >> csx
 
     def block_sum(a):
         pad = np.pad(a, ((0, ch * bh - h), (0, cw * bw - w)), mode="edge")
         return pad.reshape(ch, bh, cw, bw).sum(axis=(1, 3)).astype(F)
 
     rs, gs, bs = block_sum(ro), block_sum(go), block_sum(bo)
-    cbo = clip_floor(_fma(F(k.cbr), rs, _fma(F(k.cbg), gs, _fma(F(k.cbb), bs, F(k.cob)))), k.max_o)
-    cro = clip_floor(_fma(F(k.crr), rs, _fma(F(k.crg), gs, _fma(F(k.crb), bs, F(k.cob)))), k.max_o)
+    cbo = _clip_floor(_fma(F(k.cbr), rs, _fma(F(k.cbg), gs, _fma(F(k.cbb), bs, F(k.cob)))), k.max_o)
+    cro = _clip_floor(_fma(F(k.crr), rs, _fma(F(k.crg), gs, _fma(F(k.crb), bs, F(k.cob)))), k.max_o)
     odt = np.uint8 if dout <= 8 else np.uint16
     return [yo.astype(odt), cbo.astype(odt), cro.astype(odt)]
+
+
+def apply_yuv(table, scale, mode, k, din, dl, dout, csx, csy, planes):
+    """k: oracle.binding.YuvConsts (constants are shared data, the pixel math is separate)."""
+    rq, gq, bq = yuv_to_rgb_codes(k, csx, csy, planes)
+    return rgb_codes_to_yuv(k, dout, csx, csy, lut3d_codes(table, scale, dl, mode, rq, gq, bq))

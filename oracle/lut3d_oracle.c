@@ -359,9 +359,7 @@ static int parse_cinespace(FILE *f, orc_lut *out)
                         if (!next_float(f, &v)) CSP_FAIL(ORC_EILSEQ);
                         out_min[i] = v < out_min[i] ? v : out_min[i];
                         out_max[i] = v > out_max[i] ? v : out_max[i];
-                        out_prelut[i][j] = v;
-                        if (j > 0 && v < last) CSP_FAIL(ORC_EILSEQ);
-                        last = v;
+                        out_prelut[i][j] = v;      /* no monotonicity check on outputs: parse_cinespace has it on the inputs only */
                     }
                 } else if (npoints == 2) {
                     NEXT_LINE_CSP();

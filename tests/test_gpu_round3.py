@@ -1,0 +1,244 @@
+"""GPU tests added in round 3: the cross-device code of the one-process multi-GPU host executed on ONE GPU (test hook),
+the real two-GPU variant (skipped on one-GPU boxes), thread safety of the cached engines behind `apply_lut`, the precision
+switch through `apply_lut` and the CLI, and the round-3 kernels (planar / packed RGB on the tube design)."""
+import subprocess
+import sys
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from lut_renderer_amd import cube, frames
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _to_dev(planes, device):
+    return [torch.from_numpy(p.view(np.int16) if p.dtype == np.uint16 else p).to(device) for p in planes]
+
+
+def _to_np(tensors, like_dtype):
+    return [t.cpu().numpy().view(np.uint16) if like_dtype == np.uint16 else t.cpu().numpy() for t in tensors]
+
+
+def _assert_equal(got, want, what):
+    for i, (a, b) in enumerate(zip(got, want)):
+        if not np.array_equal(a, b):
+            diff = np.abs(a.astype(np.int64) - b.astype(np.int64))
+            bad = np.argwhere(diff > 0)
+            raise AssertionError(f"{what}: plane {i} differs at {len(bad)} samples, max |d|={diff.max()}, "
+                                 f"first {bad[0].tolist()} got {a[tuple(bad[0])]} want {b[tuple(bad[0])]}")
+
+
+# ------------------------------------------------------------------ cross-device branch, executed on one GPU
+@pytest.mark.parametrize("fmt,depth,cs,h", [("yuv420p10le", 10, (1, 1), 74), ("yuv422p10le", 10, (1, 0), 37),
+                                            ("yuv420p", 8, (1, 1), 74), ("yuv444p10le", 10, (0, 0), 37)])
+def test_group_remote_branch_runs_on_one_gpu(orc, cube_dir, fmt, depth, cs, h):
+    """`LutEngineGroup([0, 0, 0], treat_as_remote=True)`: engines 1 and 2 behave as if they sat on other GPUs -- their row
+    blocks are sliced, copied, applied as short frames of their own and copied back (multigpu.py), and the lattice reaches
+    them through hipMemcpyPeerAsync (lutr_lut_broadcast_ex, LUTR_BCAST_FORCE_PEER_COPY).  Odd block count, a height that is
+    not a multiple of the block count, 4:2:0 / 4:2:2 / 4:4:4: the chroma row ranges of every block must line up."""
+    from lut_renderer_amd.multigpu import LutEngineGroup
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    src = frames.natural_yuv(256, h, depth, cs[0], cs[1], k=51)
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", depth, depth, depth, 1 << sum(cs))
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, depth, depth, depth, cs[0], cs[1], src)
+    dt = np.uint16 if depth > 8 else np.uint8
+    with LutEngineGroup([0, 0, 0], treat_as_remote=True) as grp:
+        grp.set_lut(lut)
+        for batch in (False, True):
+            s = _to_dev(src, "cuda:0")
+            if batch:
+                s = [t.unsqueeze(0).repeat(3, 1, 1) for t in s]
+            got = grp.apply_yuv(s, pix_fmt=fmt)
+            grp.sync()
+            torch.cuda.synchronize()
+            assert grp.last_remote == 2 and len(grp.last_blocks) == 3
+            assert all("unit" in name for name in grp.last_kernels), grp.last_kernels      # the peer copies inherited the seal
+            if batch:
+                for f in range(3):
+                    _assert_equal(_to_np([t[f] for t in got], dt), want, f"remote group {fmt} frame {f}")
+            else:
+                _assert_equal(_to_np(got, dt), want, f"remote group {fmt}")
+        # a second LUT through the same group: the root waits for the peers' reads before it overwrites its lattice
+        lut2 = cube.read_cube(cube_dir / "identity_33.cube")
+        grp.set_lut(lut2)
+        grp.set_lut(lut)
+        got = grp.apply_yuv(_to_dev(src, "cuda:0"), pix_fmt=fmt)
+        grp.sync()
+        _assert_equal(_to_np(got, dt), want, f"remote group {fmt} after two more uploads")
+
+
+def test_broadcast_receiver_rebound_to_another_stream_waits_for_its_copy(orc, cube_dir):
+    """lutr_lut_broadcast records the receiver's event, so a receiver that is bound to a different stream before
+    its first apply still reads a complete lattice."""
+    from lut_renderer_amd.multigpu import LutEngineGroup
+    lut = cube.read_cube(cube_dir / "log709_65.cube")        # 4.6 MB: a copy that takes a while
+    src = frames.natural_yuv(256, 72, 10, 1, 1, k=52)
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", 10, 10, 10, 4)
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src)
+    with LutEngineGroup([0, 0], treat_as_remote=True) as grp:
+        side = torch.cuda.Stream(device="cuda:0")
+        dev = _to_dev(src, "cuda:0")
+        torch.cuda.synchronize()
+        grp.set_lut(lut)
+        with torch.cuda.stream(side):                         # the receiver's first apply runs on a stream it never saw
+            got = grp.engines[1].apply_yuv(dev, pix_fmt="yuv420p10le")
+        side.synchronize()
+        _assert_equal(_to_np(got, np.uint16), want, "receiver on a new stream")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's 8-GPU node)")
+@pytest.mark.parametrize("home", [0, 1])
+def test_group_on_two_real_gpus(orc, cube_dir, home):
+    """devices=[0, 1] with the frames resident on device `home`: peer copies over xGMI, odd heights, 4:2:0 and 4:4:4."""
+    from lut_renderer_amd.multigpu import LutEngineGroup
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    with LutEngineGroup([0, 1]) as grp:
+        grp.set_lut(lut)
+        for fmt, depth, cs, h in (("yuv420p10le", 10, (1, 1), 75), ("yuv444p10le", 10, (0, 0), 37)):
+            src = frames.natural_yuv(256, h, depth, cs[0], cs[1], k=53)
+            k = orc.yuv_constants("bt709", "tv", "bt709", "tv", depth, depth, depth, 1 << sum(cs))
+            want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, depth, depth, depth, cs[0], cs[1], src)
+            got = grp.apply_yuv(_to_dev(src, f"cuda:{home}"), pix_fmt=fmt)
+            grp.sync()
+            torch.cuda.synchronize(0); torch.cuda.synchronize(1)
+            assert grp.last_remote == 1
+            _assert_equal(_to_np(got, np.uint16), want, f"two-GPU group {fmt} home {home}")
+
+
+# ------------------------------------------------------------------ apply_lut: threads and precision
+def test_apply_lut_two_threads_two_luts_never_mix(orc, cube_dir):
+    """the reference runs tasks on a thread pool (task_manager.py:229-235) and ctypes releases the GIL.  Two
+    threads that share the cached engine, each with its own LUT, must each get their own LUT's pixels, every time."""
+    from lut_renderer_amd import api
+    luts = {name: cube.read_cube(cube_dir / name) for name in ("log709_33.cube", "identity_33.cube")}
+    src = frames.natural_yuv(512, 128, 10, 1, 1, k=54)
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", 10, 10, 10, 4)
+    want = {n: orc.apply_yuv(l.table, l.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src) for n, l in luts.items()}
+    dev = _to_dev(src, "cuda:0")
+    errors = []
+
+    def worker(name):
+        try:
+            for _ in range(25):
+                out, _tags = api.apply_lut(dev, cube=cube_dir / name, pix_fmt="yuv420p10le", colorspace="bt709",
+                                           color_range="tv")
+                _assert_equal(_to_np(out, np.uint16), want[name], f"thread {name}")
+        except Exception as exc:          # noqa: BLE001
+            errors.append(exc)
+
+    try:
+        threads = [threading.Thread(target=worker, args=(n,)) for n in luts]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[0]
+        # a direct upload on a caller-supplied engine resets apply_lut's shortcut
+        from lut_renderer_amd.engine import LutEngine
+        with LutEngine(0) as eng:
+            a = luts["log709_33.cube"]
+            out, _ = api.apply_lut(dev, cube=a, pix_fmt="yuv420p10le", colorspace="bt709", color_range="tv", engine=eng)
+            eng.set_lut(luts["identity_33.cube"])
+            out, _ = api.apply_lut(dev, cube=a, pix_fmt="yuv420p10le", colorspace="bt709", color_range="tv", engine=eng)
+            eng.sync()
+            _assert_equal(_to_np(out, np.uint16), want["log709_33.cube"], "shortcut after a direct upload")
+    finally:
+        api.close_cached_engines()
+
+
+def test_precision_is_reachable_from_apply_lut(orc, cube_dir):
+    """FAST is an engine-level option of the product path (default strict)."""
+    from lut_renderer_amd import api
+    src = frames.natural_yuv(512, 128, 10, 1, 1, k=55)
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", 10, 10, 10, 4)
+    want = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src)
+    want_fast = orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src, fast=True)
+    dev = _to_dev(src, "cuda:0")
+    try:
+        eng = api._cached_engine((0,))
+        eng.set_variant("vec_lds")
+        out, _ = api.apply_lut(dev, cube=lut, pix_fmt="yuv420p10le", colorspace="bt709", color_range="tv")
+        assert "fast" not in eng.last_kernel
+        _assert_equal(_to_np(out, np.uint16), want, "default precision is strict")
+        out, _ = api.apply_lut(dev, cube=lut, pix_fmt="yuv420p10le", colorspace="bt709", color_range="tv", precision="fast")
+        assert eng.last_kernel.rstrip(">").endswith("fast") or ",fast" in eng.last_kernel, eng.last_kernel
+        got = _to_np(out, np.uint16)
+        _assert_equal(got, want_fast, "fast == its CPU twin")
+        assert max(int(np.abs(g.astype(np.int32) - w.astype(np.int32)).max()) for g, w in zip(got, want)) <= 1
+        out, _ = api.apply_lut(dev, cube=lut, pix_fmt="yuv420p10le", colorspace="bt709", color_range="tv")
+        assert "fast" not in eng.last_kernel                # the default comes back
+        with pytest.raises(ValueError):
+            api.apply_lut(dev, cube=lut, pix_fmt="yuv420p10le", precision="half")
+    finally:
+        api.close_cached_engines()
+
+
+def test_cli_precision_option(orc, cube_dir, tmp_path):
+    src = frames.natural_yuv(256, 64, 10, 1, 1, k=56)
+    raw = tmp_path / "in.yuv"
+    raw.write_bytes(b"".join(np.ascontiguousarray(p).tobytes() for p in src) * 3)
+    lut = cube.read_cube(cube_dir / "log709_33.cube")
+    k = orc.yuv_constants("bt709", "tv", "bt709", "tv", 10, 10, 10, 4)
+    want = {"strict": orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src),
+            "fast": orc.apply_yuv(lut.table, lut.scale, "tetrahedral", k, 10, 10, 10, 1, 1, src, fast=True)}
+    for prec in ("strict", "fast"):
+        out = tmp_path / f"out_{prec}.yuv"
+        cmd = [sys.executable, "-m", "lut_renderer_amd.cli", "-y", "-i", str(raw), "-o", str(out), "--size", "256x64",
+               "--pix-fmt", "yuv420p10le", "--cube", str(cube_dir / "log709_33.cube"), "--colorspace", "bt709",
+               "--color-range", "tv", "--fps", "30000/1001", "--precision", prec]
+        env = dict(**__import__("os").environ, LUTR_SMALL_JOB_MPX="0")
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        data = np.frombuffer(out.read_bytes(), dtype=np.uint16)
+        per = sum(p.size for p in want[prec])
+        assert data.size == 3 * per
+        flat = np.concatenate([p.reshape(-1) for p in want[prec]])
+        for f in range(3):
+            assert np.array_equal(data[f * per:(f + 1) * per], flat), (prec, f)
+
+
+# ------------------------------------------------------------------ bench.py: what the driver's default line must say
+def test_bench_default_line_is_strict_with_fast_beside_it_and_carries_config5():
+    """the default run reports the reference-precision kernel as `value` (dtype f32, config.precision
+    strict), the fp16-lattice kernel only in `other_precision` (own kernel_ms, own dtype string), both precisions on the other
+    content kinds, BASELINE config 5 (`host_pipeline`, pc->tv prologue) with the PCIe rates measured in the same run, and the
+    host cost per apply."""
+    import json
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--frames", "4",
+                          "--cpu-seconds", "1", "--host-frames", "16"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["precision"] == "strict" and d["dtype"] == "f32" and "fast" not in d["config"]["kernel"]
+    o = d["other_precision"]
+    assert o["precision"] == "fast" and "f16" in o["dtype"] and o["kernel_ms"] > 0 and "fast" in o["kernel"]
+    for dist, per in d["extra_Mpx_s"].items():
+        assert set(per) == {"strict", "fast"} and per["strict"]["Mpx_s"] > 0 and "fast" in per["fast"]["kernel"], dist
+    hp = d["host_pipeline"]
+    assert hp["prologue"].startswith("scale=in_range=pc") and "pre" in hp["kernel"] and hp["frames"] == 16
+    assert hp["pcie_measured_GBps"]["each_way_concurrent"] > 1 and 0 < hp["frac_of_measured_pcie"] < 1.5
+    hc = d["host_us_per_apply"]
+    assert hc["auto"]["c_abi_us"] > 0 and hc["auto"]["python_us"] >= hc["auto"]["c_abi_us"] * 0.5 and "tile" in hc["vec_lds"]["kernel"]
+    assert d["config"]["setup_s"] >= 0
+
+
+def test_bench_six_rank_rehearsal_on_one_gpu():
+    """The N-rank control flow with the most ranks one GPU box may host (6 processes on the card; the driver's N = 8 run is
+    the same code with two more): every rank takes its row block of the shared frames, one broadcast, no data-path collective.
+    (`tests/test_shard_dist.py` checks the N = 8 partition itself: 270 rows of a UHD frame per rank.)"""
+    import json
+    import os
+    env = dict(os.environ, LUTR_DIST_BACKEND="gloo", LUTR_FORCE_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1",
+                          "--frames", "1", "--pipeline", "hbm"], env=env, capture_output=True, text=True, timeout=1100)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 6 and d["collective"]["world"] == 6 and d["collective"]["data_path_collectives"] == 0
+    assert d["strong"]["rows_per_gpu"] == 360 and d["strong"]["value"] > 0 and d["config"]["precision"] == "strict"

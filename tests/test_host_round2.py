@@ -141,3 +141,44 @@ def test_engine_stage_commands_split_build_command_around_the_engine():
         assert flag in e and e[e.index(flag) + 1] == full[full.index(flag) + 1], flag
     with pytest.raises(ValueError, match="copy"):
         engine_stage_commands(Path("a"), Path("b"), ProcessingParams(video_codec="copy"), Path("x.cube"), info)
+
+
+def test_encoder_of_the_engine_stage_carries_audio_subtitles_metadata_and_the_rational_rate():
+    """ADVICE r2: the reference's one ffmpeg process carries the source's audio / subtitles / metadata into the output
+    (ffmpeg.py:385-414) -- a raw pipe has none of them, so the encoder reads the source as a second input; and the frame rate
+    travels as ffprobe's rational, not as a six-digit float (30000/1001 vs 29.97: timestamps drift)."""
+    from lut_renderer_amd.command import fps_rational
+    from lut_renderer_amd.pipe import engine_stage_commands
+    params = ProcessingParams(video_codec="libx265", audio_codec="copy")
+    info = VideoInfo(width=1920, height=1080, bit_depth=10, pix_fmt="yuv420p10le", color_range="tv", colorspace="bt709",
+                     fps=30000 / 1001, duration=2.0)
+    c = engine_stage_commands(Path("clip.mov"), Path("out.mp4"), params, Path("look.cube"), info, python_bin="python3",
+                              precision="fast")
+    e = c.encoder
+    ins = [i for i, t in enumerate(e) if t == "-i"]
+    assert len(ins) == 2 and e[ins[0] + 1] == "pipe:0" and e[ins[1] + 1] == "clip.mov"
+    assert e[e.index("-r") + 1] == "30000/1001" and e.index("-r") < ins[0]            # an INPUT option of the raw pipe
+    maps = [e[i + 1] for i, t in enumerate(e) if t == "-map"]
+    assert maps == ["0:v:0", "1:a?", "1:s?"]
+    assert e[e.index("-map_metadata") + 1] == "1" and e[e.index("-map_chapters") + 1] == "1"
+    assert e[e.index("-c:a") + 1] == "copy" and e[-1] == "out.mp4"
+    assert c.engine[c.engine.index("--fps") + 1] == "30000/1001"
+    assert c.engine[c.engine.index("--precision") + 1] == "fast"
+    for value, text in ((25.0, "25"), (24000 / 1001, "24000/1001"), (59.94005994, "60000/1001"), (12.5, "25/2"), (50, "50")):
+        assert fps_rational(value) == text
+
+
+def test_engine_command_precision_is_an_engine_option_with_a_strict_default():
+    """VERDICT r2 #3: everything the reference's caller can reach must be able to select FAST; default strict."""
+    from lut_renderer_amd import cli
+    info = VideoInfo(width=64, height=32, bit_depth=10, pix_fmt="yuv420p10le", color_range="tv", colorspace="bt709", fps=25.0)
+    base = engine_command(Path("a.yuv"), Path("b.yuv"), ProcessingParams(), Path("x.cube"), info, python_bin="py")
+    assert "--precision" not in base
+    fast = engine_command(Path("a.yuv"), Path("b.yuv"), ProcessingParams(), Path("x.cube"), info, python_bin="py", precision="fast")
+    assert fast[fast.index("--precision") + 1] == "fast" and [t for t in fast if t not in ("--precision", "fast")] == base
+    with pytest.raises(ValueError):
+        engine_command(Path("a.yuv"), Path("b.yuv"), ProcessingParams(), Path("x.cube"), info, precision="bf16")
+    args = cli.build_parser().parse_args(fast[3:])
+    assert args.precision == "fast" and args.fps == 25.0
+    assert cli.build_parser().parse_args(base[3:]).precision == "strict"
+    assert abs(cli.build_parser().parse_args(base[3:] + ["--fps", "30000/1001"]).fps - 29.97002997) < 1e-6

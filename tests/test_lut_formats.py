@@ -203,6 +203,15 @@ def test_csp_prelut_is_resampled_like_lut3d_and_both_readers_agree(orc, tmp_path
         cube.read_lut(bad)
     with pytest.raises(orc.OracleError):
         orc.parse_lut_file_ex(bad)
+    # ... but only the INPUT points must rise: an inverting / non-monotonic OUTPUT side loads in lut3d, and here
+    inv = tmp_path / "inverting.csp"
+    _csp_with_prelut(inv, n, tab, [(np.array([0.0, 0.25, 0.5, 1.0]), np.array([1.0, 0.4, 0.6, 0.0]))] * 3)
+    li = cube.read_lut(inv)
+    ni, si, ti, prei = orc.parse_lut_file_ex(inv)
+    assert li.prelut is not None and np.array_equal(li.prelut.table, prei.table) and np.array_equal(li.table, ti)
+    # last entry: x = 1 sits in the last interval [0.5, 1] and the mix is the UNNORMALISED distance 0.5: 0.6 + (0 - 0.6) * 0.5
+    assert li.prelut.table[0, 0] == np.float32(1.0)
+    assert li.prelut.table[0, 65535] == np.float32(0.6) + (np.float32(0.0) - np.float32(0.6)) * np.float32(0.5)
     short = tmp_path / "short.csp"
     short.write_text("CSPLUTV100\n3D\n\n4\n0.0 0.5 1.0\n")
     with pytest.raises(_native.LutrError):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/configs_sweep.sh -- one bench line per BASELINE.json config / format family (1 GPU), as a table.
-# Column "other" = the other precision (strict when the line ran fast) timed on the same batch.
-run() { timeout -k 10 200 python bench.py --no-cpu-baseline --no-extra --steps 40 --warmup 10 "$@" 2>/dev/null | python -c "
+# Column "other" = the other precision (fast when the line ran strict, the default) timed on the same batch.
+run() { timeout -k 10 200 python bench.py --lean --steps 40 --warmup 10 "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']; w=c.get('lds_window') or {}; o=d.get('other_precision') or {}
 wl=c['workload'].split(',')[0]

@@ -6,7 +6,7 @@ for n in "$@"; do
   O=$R/gpurun_out/prof_insts_$n; rm -rf $O; mkdir -p $O
   lib=$R/lut_renderer_amd/lib/liblutr_$n.so; [ "$n" = base ] && lib=$R/lut_renderer_amd/lib/liblutr.so
   export LUTR_LIBRARY=$lib
-  timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stats --no-extra --no-other --no-strong > $O/log.txt 2>&1
+  timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O -- python3 bench.py --steps 4 --warmup 2 --lean --no-stats --no-other > $O/log.txt 2>&1
   python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(list)

@@ -6,7 +6,7 @@
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O; cd $R
-ARGS="--steps 12 --warmup 4 --no-cpu-baseline --no-stats --no-extra --no-other $@"
+ARGS="--steps 12 --warmup 4 --lean --no-stats --no-other $@"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py $ARGS > $O/kt.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py $ARGS > $O/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py $ARGS > $O/write.log 2>&1

@@ -1,4 +1,4 @@
-run() { timeout -k 10 100 python bench.py --no-cpu-baseline --no-extra --no-strong --no-stats --no-other --fmt gbrp10le --frames 128 --steps 40 --warmup 10 2>/dev/null | tail -1 | python -c "
+run() { timeout -k 10 100 python bench.py --lean --no-stats --no-other --fmt gbrp10le --frames 128 --steps 40 --warmup 10 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$1 %6.1f Gpx/s %5.0f GB/s' % (d['value']/1e3, d['roofline']['achieved']))"; }
 run base

@@ -25,6 +25,7 @@ for f in sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")))[-1:]:
                                for r in rows[:3]]
 for f in sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_trace.csv")))[-1:]:
     rows = [r for r in csv.DictReader(open(f)) if "lutr::" in r["Kernel_Name"] and "make_lat16" not in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     summary["dispatch_us"] = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1) for r in rows]
 counters = defaultdict(list)
 kernel = None
@@ -54,10 +55,30 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         "total_corrected": 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024,
         "note": "FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM); WRITE_SIZE exact"}
 line = (src / "bench_line.json")
+steps = None
 if line.exists() and line.read_text().strip():
     b = json.loads(line.read_text())
     summary["bench"] = {k: b[k] for k in ("value", "ms_per_step", "roofline", "config")}
     summary["workload_tag"] = tag
+    steps = int(b.get("steps", 0)) or None
+# The profiler's own average (kernel_stats AverageNs) runs over EVERY dispatch of the kernel, including bench.py's untimed
+# clock-ramp and warm-up launches, which are 10-25 % slower (the GPU leaves its idle clock after ~20 ms of load).  What the
+# bench line times is the LAST `steps` dispatches: report those, and the median, so that the figures here and the driver's
+# step time describe the same launches.
+d = summary.get("dispatch_us") or []
+if d:
+    timed = d[-steps:] if steps and len(d) >= steps else d
+    srt = sorted(d)
+    summary["kernel_time_us"] = {
+        "dispatches": len(d), "mean_all": round(sum(d) / len(d), 1), "median_all": srt[len(srt) // 2], "min": srt[0],
+        "timed_dispatches": len(timed), "mean_timed": round(sum(timed) / len(timed), 1),
+        "median_timed": sorted(timed)[len(timed) // 2],
+        "note": "mean_timed = the last `steps` dispatches (the ones bench.py times); mean_all includes clock-ramp launches"}
+    if "bench" in summary:
+        alg = summary["bench"]["roofline"].get("algorithmic_bytes_per_launch")
+        if alg:
+            t = summary["kernel_time_us"]["mean_timed"] * 1e-6
+            summary["kernel_time_us"]["roofline_frac_from_profile"] = round(alg / t / 1e9 / summary["bench"]["roofline"]["peak"], 4)
 (dst / f"{rnd}_{tag}_counters.json").write_text(json.dumps(summary, indent=1) + "\n")
 if "hbm_bytes_per_launch" in summary and len(sys.argv) > 3:
     tpath = dst / "traffic.json"
