@@ -68,6 +68,9 @@
                                   // sums -- bit-identical, 14 % fewer VALU instructions in the strict body (68.2 -> 58.7 per pixel), and
                                   // 1-2 % SLOWER: a packed op holds the fp32 pipe as long as the two scalar ops it replaces (4.6 vs 2 x 2.5 cycles)
 #endif
+#ifndef LUTR_T2_NODE16
+#define LUTR_T2_NODE16 0          // 1: strict 4-tap kernels stage float4 nodes (one ds_read_b128 per tap, 4 LDS cycles) instead of 12-byte ones (ds_read2_b32 + ds_read_b32, 6 cycles)
+#endif
 #ifndef LUTR_T2_PHASES
 #define LUTR_T2_PHASES 1          // scheduling barriers between the load and use phases of a pixel group (tile_body)
 #endif
@@ -175,7 +178,7 @@ template <int INTERP, int V> struct Node {
     static constexpr bool fast = V == V_FAST;
     // bytes per node in a window: fast = four fp16 {r,g,b,-} (one ds_read_b64 per tap); strict 4-tap modes pack fp32 {r,g,b}
     // (a third more nodes per wave than float4; a tap is ds_read2_b32 + ds_read_b32); strict trilinear reads float4 nodes
-    static constexpr int lds = fast ? 8 : (INTERP == LUTR_INTERP_TRILINEAR ? 16 : 12);
+    static constexpr int lds = fast ? 8 : ((INTERP == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
     static constexpr int glb = fast ? 8 : 16;                                              // bytes per node in HBM/L2
 };
 
@@ -1654,7 +1657,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     tg.ch = ch; tg.nrc = (tg.nry + ch - 1) / ch; tg.nchunks = G.nframes * tg.nrc * tg.nsx;
     tg.tab_entries = vv >= V_TAB ? table_entries(K, din) : 0;
     tg.max_raw = (1 << din) - 1;
-    const int node = vv == V_FAST ? 8 : (mode == LUTR_INTERP_TRILINEAR ? 16 : 12);
+    const int node = vv == V_FAST ? 8 : ((mode == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
     const int blocks_per_cu = waves_per_cu / LUTR_T2_WPB > 0 ? waves_per_cu / LUTR_T2_WPB : 1;
     const int lds_block = 163840 / blocks_per_cu - tg.tab_entries * 8 - 64 * LUTR_T2_WPB;
     // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS
@@ -1679,10 +1682,13 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         const float kappa = L.sc[0] * L.scale_f;
         const float eps = K.max_l * (1.0f / 2097152.0f) + 1e-3f;                 // as map_box
         const float slack = 1.0f + 2.0f * L.lut_max * (1.0f / 2097152.0f) + 2e-3f;
+        int min_win = 256, tube_pct = 70;
+        if (const char *e = getenv("LUTR_MIN_WIN")) { const int c = atoi(e); if (c >= 128 && c <= 4096) min_win = c; }
+        if (const char *e = getenv("LUTR_TUBE_PCT")) { const int c = atoi(e); if (c >= 10 && c <= 95) tube_pct = c; }
         while (h >= 3) {
             const long long nb = 2 * h + 3, bytes = (long long)L.n1 * nb * nb * node;
             const float t = ((float)(h + 1) - slack) / kappa - 1.0f - eps;
-            if (bytes <= (long long)lds_block * 7 / 10 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= 256 && t > 0.0f) {
+            if (bytes <= (long long)lds_block * tube_pct / 100 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= min_win && t > 0.0f) {
                 tg.tube_h = h; tg.tube_t = t; tube_bytes = bytes;
                 break;
             }
