@@ -129,7 +129,9 @@ def apply_lut(planes: Sequence, *, cube, interp: str = "tetrahedral", pix_fmt: s
                               zscale_dither=zscale_dither)
     info = VideoInfo(width=width, height=height, pix_fmt=pix_fmt, bit_depth=infer_bit_depth(pix_fmt),
                      colorspace=colorspace, color_range=color_range)
-    plan = resolve_lut_plan(params, cube if cube is not None else "engine.cube", info)
+    # (the plan only carries the path into the filter string / notes; a parsed CubeLut or an engine that already holds the
+    # lattice has none)
+    plan = resolve_lut_plan(params, cube if isinstance(cube, (str, Path)) else "engine.cube", info)
     kw = engine_call_for(plan, pix_fmt, out_pix_fmt)
     # ffmpeg.py:305-307: any value other than "error_diffusion" leaves the chain without a dither filter
     kw["dither"] = "error_diffusion" if getattr(params, "zscale_dither", "none") == "error_diffusion" else "none"

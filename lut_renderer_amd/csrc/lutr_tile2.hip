@@ -68,6 +68,12 @@
                                   // sums -- bit-identical, 14 % fewer VALU instructions in the strict body (68.2 -> 58.7 per pixel), and
                                   // 1-2 % SLOWER: a packed op holds the fp32 pipe as long as the two scalar ops it replaces (4.6 vs 2 x 2.5 cycles)
 #endif
+#ifndef LUTR_T2_TUBE_BG
+#define LUTR_T2_TUBE_BG 1         // the tube's second difference axis: 1 = (b - g), 0 = (b - r) as in round 2.  With BT.709 / 601 / 2020
+                                  // g - r is almost -Cr and b - g almost +Cb (dG = -0.21 cb - 2.33 cr, dBG = 2.33 cb + 0.53 cr at 10 bit),
+                                  // so the tube's cross-section is a near-square in the chroma plane; b - r = 2.12 cb - 1.80 cr makes it a
+                                  // parallelogram stretched along the magenta-green diagonal and thin along orange-blue, where video lives
+#endif
 #ifndef LUTR_T2_NODE16
 #define LUTR_T2_NODE16 0          // 1: strict 4-tap kernels stage float4 nodes (one ds_read_b128 per tap, 4 LDS cycles) instead of 12-byte ones (ds_read2_b32 + ds_read_b32, 6 cycles)
 #endif
@@ -159,6 +165,8 @@ struct Geom {
     int tube_h;           // > 0: a workgroup-shared "grey tube" of the lattice is staged once, behind the scratch area: every cell with
                           // |pg - pr| <= tube_h and |pb - pr| <= tube_h, all of r.  Tiles whose chroma keeps them inside it (tube_holds)
                           // need no window at all; the per-wave windows serve the saturated rest.
+    int tube_plane;       // nodes from one r plane of the tube to the next: (2 tube_h + 3)^2 plus a few nodes of padding chosen by the
+                          // launcher so that cells one step apart on any two axes never share an LDS bank (tube_plane_stride)
     float tube_t;         // the test: |gv - rv| and |bu - rv| (RGB codes, chroma only) must stay <= tube_t over the lane's unit
     unsigned tube_rlo, tube_rhi;   // a raw chroma interval [lo, hi] (packed like the window boxes) that implies the test for both planes:
                                    // four saturating subtractions instead of ~35 VALU for the tiles that fit it (tube_rlo > tube_rhi: none)
@@ -563,7 +571,9 @@ DEV bool tube_holds(const YuvConsts &K, const Geom &TG, const Ext &e)
     // krv, kbu > 0; kgu, kgv < 0 for every matrix (make_yuv_consts)
     const float rv0 = K.krv * crd0, rv1 = K.krv * crd1, bu0 = K.kbu * cbd0, bu1 = K.kbu * cbd1;
     const float gv0 = fma_(K.kgu, cbd1, K.kgv * crd1), gv1 = fma_(K.kgu, cbd0, K.kgv * crd0);      // min, max
-    const float dg0 = gv0 - rv1, dg1 = gv1 - rv0, db0 = bu0 - rv1, db1 = bu1 - rv0;
+    // (b - g: bu - gv rises in cb and in cr, its extremes sit at the corners (cb0, cr0) and (cb1, cr1) where gv is gv1 and gv0)
+    const float dg0 = gv0 - rv1, dg1 = gv1 - rv0;
+    const float db0 = LUTR_T2_TUBE_BG ? bu0 - gv1 : bu0 - rv1, db1 = LUTR_T2_TUBE_BG ? bu1 - gv0 : bu1 - rv0;
     const float worst = vmax3(fmaxf(-dg0, dg1), -db0, db1);
     return __all(worst <= TG.tube_t);
 }
@@ -585,7 +595,7 @@ DEV bool tube_holds_samples(const YuvConsts &K, const Geom &TG, const TileIn<WIN
         }
         const float cbd = cbv - K.coff, crd = crv - K.coff;
         const float rv = K.krv * crd, gv = fma_(K.kgu, cbd, K.kgv * crd), bu = K.kbu * cbd;
-        worst = vmax3(worst, fabsf(gv - rv), fabsf(bu - rv));
+        worst = vmax3(worst, fabsf(gv - rv), fabsf(LUTR_T2_TUBE_BG ? bu - gv : bu - rv));
     }
     return __all(worst <= TG.tube_t);
 }
@@ -1266,14 +1276,16 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         __syncthreads();
     }
     const int tube_nb = 2 * TG.tube_h + 3;                    // nodes across each difference axis: cells -H..H, corners -H-1..H+1
-    const int tube_nodes = TG.tube_h > 0 ? L.n1 * tube_nb * tube_nb : 0;
+    const int tube_nodes = TG.tube_h > 0 ? L.n1 * TG.tube_plane : 0;
     if (TG.tube_h > 0) {
-        // node (ir, ig, ib) = lattice (r, r + ig - H - 1, r + ib - H - 1), clamped (a clamped node is never read by a valid pixel)
+        // node (ir, ig, ib) = lattice (r, g = r + ig - H - 1, b = g + ib - H - 1) [b = r + ib - H - 1 without LUTR_T2_TUBE_BG], clamped
+        // (a clamped node is never read by a valid pixel)
         char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
-        const int plane = tube_nb * tube_nb, nmax = L.n1 - 1;
+        const int plane = TG.tube_plane, nmax = L.n1 - 1;
         for (int i = threadIdx.x; i < tube_nodes; i += 64 * LUTR_T2_WPB) {
-            const int ir = i / plane, rem = i - ir * plane, ig = rem / tube_nb, ib = rem - ig * tube_nb;
-            const int g = min(max(ir + ig - TG.tube_h - 1, 0), nmax), b = min(max(ir + ib - TG.tube_h - 1, 0), nmax);
+            const int ir = i / plane, rem = i - ir * plane, ig = min(rem / tube_nb, tube_nb - 1), ib = rem - ig * tube_nb;   // (padding: any node)
+            const int gq = ir + ig - TG.tube_h - 1;
+            const int g = min(max(gq, 0), nmax), b = min(max((LUTR_T2_TUBE_BG ? gq : ir) + ib - TG.tube_h - 1, 0), nmax);
             const int src = (ir * L.n1 + g) * L.n1 + b;
             if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[src];
             else {
@@ -1291,7 +1303,9 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     const int tube_off = tab_bytes + LUTR_T2_WPB * 64;
     const int slice_off = tube_off + tube_nodes * N::lds + wib * TG.win_nodes * N::lds;
     Win Wt;                                                   // the tube as a window: same address form as a staged one
-    Wt.o_g = N::lds * tube_nb; Wt.o_r = N::lds * (tube_nb * tube_nb - tube_nb - 1);
+    // index = pr * plane + (pg - pr + H + 1) * nb + (pb - pg + H + 1)   [(pb - pr + H + 1) without LUTR_T2_TUBE_BG]
+    if (LUTR_T2_TUBE_BG) { Wt.o_g = N::lds * (tube_nb - 1); Wt.o_r = N::lds * (TG.tube_plane - tube_nb); }
+    else { Wt.o_g = N::lds * tube_nb; Wt.o_r = N::lds * (TG.tube_plane - tube_nb - 1); }
     Wt.fr = (float)Wt.o_r; Wt.fg = (float)Wt.o_g; Wt.fb = (float)N::lds;
     Wt.fc = (float)(lds_base() + tube_off + N::lds * ((TG.tube_h + 1) * tube_nb + TG.tube_h + 1));
     unsigned st_tube = 0;
@@ -1578,6 +1592,30 @@ int table_entries(const YuvConsts &K, int din)
     return ((int)top + 3) & ~1;           // even: the window slices behind the table stay 16-byte aligned (ds_read_b128)
 }
 
+// Nodes between two r planes of the tube.  The lanes of a wave read cells that are mostly one step apart (neighbouring pixels):
+// with node index = pr * A + pg * B + pb two of them collide in the LDS banks when dr * A + dg * B + db is a multiple of 32 (a tap
+// read is 32 lanes per pass, the bank is the dword address mod 32 or 64, node strides of 2 or 3 dwords are invertible mod 32).
+// The unpadded 15 x 15 and 17 x 17 planes of the strict kernels' tubes have exactly that for (dr, dg) = +-(1, 1): every luma step
+// that moves r and g but not b costs a second LDS pass.  A few nodes of padding per plane remove it.
+int tube_plane_stride(int nb)
+{
+    int best = nb * nb, best_bad = 1 << 30;
+    for (int pad = 0; pad < 12; pad++) {
+        const int plane = nb * nb + pad;
+        const int A = LUTR_T2_TUBE_BG ? plane - nb : plane - nb - 1, B = LUTR_T2_TUBE_BG ? nb - 1 : nb;
+        int bad = 0;
+        for (int dr = -2; dr <= 2; dr++)
+            for (int dg = -2; dg <= 2; dg++)
+                for (int db = -2; db <= 2; db++) {
+                    if (!dr && !dg && !db) continue;
+                    if (((dr * A + dg * B + db) & 31) == 0) bad += (abs(dr) <= 1 && abs(dg) <= 1 && abs(db) <= 1) ? 100 : 1;
+                }
+        if (bad < best_bad) { best_bad = bad; best = plane; }
+        if (!bad) break;
+    }
+    return best;
+}
+
 bool out_clip_dead(const YuvConsts &K, int chroma_n)
 {
     const float m = K.max_l, mn = K.max_l * (float)chroma_n;
@@ -1670,7 +1708,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     // H = 5 / 7 / 8 / 9: natural frames 611 / 620 / 628 / 636 Gpx/s, three times the chroma 516 / 521 / 530 / 519, sigma = 8 noise
     // 503 / 543 / 550 / 569, sigma = 16 250 / 388 / 481 / 500: the tube, not the windows, is what carries natural content; 9 leaves
     // windows of 197 nodes and starts to cost saturated frames.  The strict kernels (12-byte nodes) get H = 6.
-    tg.tube_h = 0; tg.tube_t = 0.0f;
+    tg.tube_h = 0; tg.tube_t = 0.0f; tg.tube_plane = 0;
     long long tube_bytes = 0;
     // (65^3: a tube that fits is 5 of ITS cells wide, +-20 8-bit codes -- 497 / 427 Gpx/s with it, 530 / 492 without: off above 40^3)
     if (!tg.whole && vv >= V_TAB && mode != LUTR_INTERP_NEAREST && (L.n1 <= 41 || getenv("LUTR_TUBE_H"))) {
@@ -1686,10 +1724,11 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         if (const char *e = getenv("LUTR_MIN_WIN")) { const int c = atoi(e); if (c >= 128 && c <= 4096) min_win = c; }
         if (const char *e = getenv("LUTR_TUBE_PCT")) { const int c = atoi(e); if (c >= 10 && c <= 95) tube_pct = c; }
         while (h >= 3) {
-            const long long nb = 2 * h + 3, bytes = (long long)L.n1 * nb * nb * node;
+            const long long nb = 2 * h + 3, plane = getenv("LUTR_TUBE_NOPAD") ? nb * nb : tube_plane_stride((int)nb);
+            const long long bytes = (long long)L.n1 * plane * node;
             const float t = ((float)(h + 1) - slack) / kappa - 1.0f - eps;
             if (bytes <= (long long)lds_block * tube_pct / 100 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= min_win && t > 0.0f) {
-                tg.tube_h = h; tg.tube_t = t; tube_bytes = bytes;
+                tg.tube_h = h; tg.tube_t = t; tg.tube_plane = (int)plane; tube_bytes = bytes;
                 break;
             }
             h--;
@@ -1699,7 +1738,8 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     if (tg.tube_h > 0) {
         // the square |cb' - coff|, |cr' - coff| <= R (after the prologue) inside the tube's chroma region: both differences are linear in
         // the two offsets, so their worst corners bound them; 1 % and one code of margin absorb the float rounding of the per-lane form
-        const float s1 = fabsf(K.kgu) + fabsf(K.kgv - K.krv), s2 = fabsf(K.kbu) + fabsf(K.krv);
+        const float s1 = fabsf(K.kgu) + fabsf(K.kgv - K.krv);
+        const float s2 = LUTR_T2_TUBE_BG ? fabsf(K.kbu - K.kgu) + fabsf(K.kgv) : fabsf(K.kbu) + fabsf(K.krv);
         const float R = floorf(0.99f * tg.tube_t / fmaxf(s1, s2)) - 1.0f;
         int lo = -1, hi = -1;
         for (int raw = 0; raw <= tg.max_raw; raw++) {               // the prologue is a monotone map of raw codes
@@ -1730,8 +1770,8 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         TP.sfs[i] = (unsigned long long)P.sfs[i]; TP.dfs[i] = (unsigned long long)P.dfs[i];
     }
     if (getenv("LUTR_DEBUG"))
-        fprintf(stderr, "[lutr t2] nsx %d nry %d chunk %d chunks %d blocks %u lds/block %zu win_nodes %d tab %d variant %d tube h %d t %.1f\n",
-                tg.nsx, tg.nry, tg.ch, tg.nchunks, grid.x, lds, tg.win_nodes, tg.tab_entries, vv, tg.tube_h, tg.tube_t);
+        fprintf(stderr, "[lutr t2] nsx %d nry %d chunk %d chunks %d blocks %u lds/block %zu win_nodes %d tab %d variant %d tube h %d plane %d t %.1f\n",
+                tg.nsx, tg.nry, tg.ch, tg.nchunks, grid.x, lds, tg.win_nodes, tg.tab_entries, vv, tg.tube_h, tg.tube_plane, tg.tube_t);
 
 #define T2_LAUNCH(WI, WO, X, Y, I, PR, VV, NAME) \
     do { \
