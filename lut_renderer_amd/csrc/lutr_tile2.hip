@@ -448,12 +448,14 @@ DEV Cells map_box(const LutConsts &L, const YuvConsts &K, const Geom &TG, float 
     const float pb0 = cell_of<INTERP, PRE, V>(L, qclip(vb0, m), 2, te), pb1 = cell_of<INTERP, PRE, V>(L, qclip(vb1, m), 2, te);
     Cells c;
     c.r0 = (int)pr0; c.r1 = (int)pr1;
-    float g_lo = pg0 - pr1, g_hi = pg1 - pr0, b_lo = pb0 - pr1, b_hi = pb1 - pr0;               // interval arithmetic
+    // the second difference axis is (b - g) [LUTR_T2_TUBE_BG] or (b - r)
+    float g_lo = pg0 - pr1, g_hi = pg1 - pr0;                                                   // interval arithmetic
+    float b_lo = LUTR_T2_TUBE_BG ? pb0 - pg1 : pb0 - pr1, b_hi = LUTR_T2_TUBE_BG ? pb1 - pg0 : pb1 - pr0;
     if (L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2]) {
         // chroma-only difference terms at the corners that extremise them: gv - rv falls in cb and in cr;
-        // bu - rv rises in cb and falls in cr
+        // bu - rv rises in cb and falls in cr; bu - gv rises in both (gv1 = gv at (cb0, cr0), gv0 = gv at (cb1, cr1))
         float dg0 = gv0 - rv1, dg1 = gv1 - rv0;
-        float db0 = bu0 - rv1, db1 = bu1 - rv0;
+        float db0 = LUTR_T2_TUBE_BG ? bu0 - gv1 : bu0 - rv1, db1 = LUTR_T2_TUBE_BG ? bu1 - gv0 : bu1 - rv0;
         const bool clips = vr0 < 0.0f || vg0 < 0.0f || vb0 < 0.0f || vr1 >= m + 1.0f || vg1 >= m + 1.0f || vb1 >= m + 1.0f;
         if (clips) { dg0 = fminf(dg0, 0.0f); dg1 = fmaxf(dg1, 0.0f); db0 = fminf(db0, 0.0f); db1 = fmaxf(db1, 0.0f); }
         const float kappa = L.sc[0] * L.scale_f;
@@ -518,7 +520,7 @@ DEV Bnd tile_bounds(const LutConsts &L, const YuvConsts &K, const Geom &TG, Tile
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-        for (int q = 0; q < NQ; q++) { hg[q] = pg_[q] - pr[q]; hb[q] = pb_[q] - pr[q]; }
+        for (int q = 0; q < NQ; q++) { hg[q] = pg_[q] - pr[q]; hb[q] = pb_[q] - (LUTR_T2_TUBE_BG ? pg_[q] : pr[q]); }
         if constexpr (T::BH * T::BW >= 2) {
 #pragma unroll
             for (int q = 0; q + 1 < T::BH * T::BW; q += 2) {
@@ -670,6 +672,26 @@ DEV bool rebox(const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext
 // first-level test of the following tiles runs against (it may come out empty for very noisy content; those tiles then
 // pay the second level).  Returns false (W untouched; the caller runs the global-gather body for this tile) when the
 // tile's colours do not fit a window, or a raw code lies above 2^din - 1.
+// Plane stride of a window: the smallest stride >= `nodes` for which cells one step apart on any axes never share an LDS bank
+// (see tube_plane_stride in the launcher: node index = pr * A + pg * B + pb, collision when dr A + dg B + db = 0 mod 32).
+DEV int win_plane_stride(int nodes, int nb)
+{
+    const int B = LUTR_T2_TUBE_BG ? nb - 1 : nb;
+#pragma unroll 1
+    for (int pad = 0; pad < 8; pad++) {
+        const int sr = nodes + pad, A = LUTR_T2_TUBE_BG ? sr - nb : sr - nb - 1;
+        bool bad = false;
+#pragma unroll 1
+        for (int k = 1; k < 27 && !bad; k++) {                   // (dr, dg, db) in {-1, 0, 1}^3 up to sign: k and 26 - k are opposite
+            const int dr = k % 3 - 1, dg = (k / 3) % 3 - 1, db = k / 9 - 1;
+            if (k == 13) continue;
+            bad = ((dr * A + dg * B + db) & 31) == 0;
+        }
+        if (!bad) return sr;
+    }
+    return nodes | 1;
+}
+
 template <int WIN, int INTERP, int PRE, int V>
 DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext &e_, const Bnd &bn_, int slice_off,
                  int scratch_off, int lane)
@@ -715,7 +737,7 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
         // odd row and plane strides: the nodes of neighbouring cells (the ones a wave reads together) differ by +-1, +-nb,
         // +-(sr - nb - 1) and small sums of those -- kept away from multiples of 16 nodes, i.e. from the same LDS banks
         const int nb_ = need_b | 1;
-        const int sr_ = (need_g * nb_) | 1, nr_ = cap / sr_;
+        const int sr_ = win_plane_stride(need_g * nb_, nb_), nr_ = cap / sr_;
         if (nr_ < need_r) continue;
         ng = need_g; nb = nb_; sr = sr_; nr = nr_;
         r0 = uni(c.r0) - ((nr - need_r) >> 1); g0 = uni(c.g0) - 1; b0 = uni(c.b0) - 1;
@@ -743,7 +765,7 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
         int spare = 1;
         for (;;) {                                   // one spare cell on each side of the chroma-like axes if it fits
             ng = need_g + 2 * spare; nb = (need_b + 2 * spare) | 1;
-            sr = (ng * nb) | 1;
+            sr = win_plane_stride(ng * nb, nb);
             nr = cap / sr;
             if (nr >= need_r + 2 * spare || spare == 0) break;
             spare--;
@@ -772,7 +794,7 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
             const int i = min(base + k * 64 + lane, total - 1);              // the last batch re-reads the final node: harmless
             const int ir = (int)(((float)i + 0.5f) * rcp_plane), rem = i - __mul24(ir, plane);
             const int ig = (int)(((float)rem + 0.5f) * rcp_nb), ib = rem - __mul24(ig, nb);
-            int r = r0 + ir, g = r + g0 + ig, b = r + b0 + ib;
+            int r = r0 + ir, g = r + g0 + ig, b = (LUTR_T2_TUBE_BG ? g : r) + b0 + ib;
             // nodes outside the cube are never referenced by a valid pixel: clamp to stay inside the lattice
             r = min(max(r, 0), nmax); g = min(max(g, 0), nmax); b = min(max(b, 0), nmax);
             const int src = __mul24(__mul24(r, n1) + g, n1) + b;
@@ -792,8 +814,9 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
         *(float4 *)(smem + scratch_off) = make_float4((float)wr0, (float)wg0, (float)wb0, (float)wr1);
         *(float2 *)(smem + scratch_off + 16) = make_float2((float)wg1, (float)wb1);
     }
-    // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pr-b0)
-    W.o_r = kLN * (sr - nb - 1); W.o_g = kLN * nb;
+    // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pg-b0)     [(pb-pr-b0) without LUTR_T2_TUBE_BG]
+    if (LUTR_T2_TUBE_BG) { W.o_r = kLN * (sr - nb); W.o_g = kLN * (nb - 1); }
+    else { W.o_r = kLN * (sr - nb - 1); W.o_g = kLN * nb; }
     W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)kLN;
     W.fc = (float)(lds_base() + slice_off - kLN * (r0 * sr + g0 * nb + b0));
     if (lane == 0) {
@@ -1720,7 +1743,10 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         const float kappa = L.sc[0] * L.scale_f;
         const float eps = K.max_l * (1.0f / 2097152.0f) + 1e-3f;                 // as map_box
         const float slack = 1.0f + 2.0f * L.lut_max * (1.0f / 2097152.0f) + 2e-3f;
-        int min_win = 256, tube_pct = 70;
+        // fast (8-byte nodes): at most 70 % of the block's LDS and windows of >= 256 nodes (H = 8 / 367 at 33^3).  The strict 4-tap
+        // kernels' 12-byte nodes do not fit that at H = 7; they trade window size for tube width (H = 7, 16 windows of 139 nodes
+        // instead of H = 6 / 277): natural +2 %, sigma-8 +0 %, sigma-16 +43 %, three times the chroma -7 % (profiles/r03_exp4.txt)
+        int min_win = node == 12 ? 128 : 256, tube_pct = node == 12 ? 85 : 70;
         if (const char *e = getenv("LUTR_MIN_WIN")) { const int c = atoi(e); if (c >= 128 && c <= 4096) min_win = c; }
         if (const char *e = getenv("LUTR_TUBE_PCT")) { const int c = atoi(e); if (c >= 10 && c <= 95) tube_pct = c; }
         while (h >= 3) {
