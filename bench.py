@@ -511,7 +511,7 @@ def main():
     wall, kern = time_steps(eng, job, src, dst, args.interp, args.steps, args.warmup, world, r0, r1 - r0)
     kernel_name = eng.last_kernel
     tile_stats = None
-    if "tile" in kernel_name and not args.no_stats:   # one extra, untimed pass with the window counters armed
+    if ("tile" in kernel_name or "tube" in kernel_name) and not args.no_stats:   # one extra, untimed pass with the window counters armed
         eng.tile_stats(True)
         job.apply(eng, src, dst, args.interp, r0, r1 - r0)
         tile_stats = eng.tile_stats(False)

@@ -697,7 +697,7 @@ int lutr_apply_packed_rgb(lutr_ctx *c, int pfmt, int interp, int w, int h, int n
     P.ss = src->stride; P.ds = dst->stride;
     P.sfs = src->frame_stride; P.dfs = dst->frame_stride;
     P.ro = ro; P.go = go; P.bo = bo; P.ao = nc == 4 ? 6 - ro - go - bo : 3;
-    return finish_launch(c, launch_packed(c->stream, c->variant, L, P, G, wide, nc, interp));
+    return finish_launch(c, launch_packed(c->stream, c->variant, L, P, G, wide, nc, interp, c->stats, c->queue));
 }
 
 int lutr_apply_yuv(lutr_ctx *c, const lutr_yuv_params *p, int interp, int w, int h, int nframes,

@@ -88,7 +88,15 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
 
 // packed RGB (lutr_packed.hip)
 const char *launch_packed(hipStream_t st, int variant, const LutConsts &L, const PackedSet &P, const FrameGeom &G,
-                          int wide, int ncomp, int interp);
+                          int wide, int ncomp, int interp, unsigned *stats, unsigned *queue);
+
+// round-3 RGB tube kernels (lutr_rgb2.hip, one translation unit per layout): planes in SLOT order -- planar callers pass
+// (R, G, B), packed callers the one buffer in [0] and rev = 1 for B, G, R memory order; nullptr = cannot take the call
+#define LUTR_R2_DECL(ly) \
+    const char *launch_rgb_tube_ly##ly(hipStream_t st, const LutConsts &L, const PlaneSet &P, const FrameGeom &G, int depth, \
+                                       int mode, int rev, unsigned *stats, unsigned *queue);
+LUTR_R2_DECL(0) LUTR_R2_DECL(1) LUTR_R2_DECL(2) LUTR_R2_DECL(3) LUTR_R2_DECL(4) LUTR_R2_DECL(5) LUTR_R2_DECL(6) LUTR_R2_DECL(7)
+#undef LUTR_R2_DECL
 
 // error-diffusion dither path (lutr_dither.hip): whole frames, float planes in F
 const char *launch_yuv_dither(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P,

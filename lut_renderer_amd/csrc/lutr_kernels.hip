@@ -241,8 +241,26 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     for (int c = 0; c < 3 && vec_ok; c++)
         vec_ok = planes_aligned(P, c, 16, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
-    if (tiles && vec_ok && ((variant == VAR_AUTO && !small_job(px)) || variant == VAR_VEC_LDS))
+    if (tiles && vec_ok && ((variant == VAR_AUTO && !small_job(px)) || variant == VAR_VEC_LDS)) {
+        // round 3: the tube kernels (lutr_rgb2.hip) take the planes in (R, G, B) order; gbrp is (G, B, R)
+        // Policy (profiles/r03_exp6*.txt): planar frames in 16-bit containers are memory-side and the round-1 kernel already moves
+        // them at the box's copy rate (gbrp10le 5.2-5.4 TB/s); the tube kernel wins on 8-bit planes for the 4-tap modes
+        // (gbrp tetrahedral 594 -> 637 Gpx/s).  LUTR_RGB2=all sends everything it can take to the tube kernels, =0 nothing.
+        const char *pol = getenv("LUTR_RGB2");
+        const bool all = pol && pol[0] == 'a', none = (pol && pol[0] == '0') || getenv("LUTR_NO_RGB2");
+        if (!none && (all || (!wide && mode != LUTR_INTERP_TRILINEAR))) {
+            PlaneSet Q = P;
+            const int from[3] = {2, 0, 1};
+            for (int k = 0; k < 3; k++) {
+                Q.s[k] = P.s[from[k]]; Q.d[k] = P.d[from[k]]; Q.ss[k] = P.ss[from[k]]; Q.ds[k] = P.ds[from[k]];
+                Q.sfs[k] = P.sfs[from[k]]; Q.dfs[k] = P.dfs[from[k]];
+            }
+            const char *name = wide ? launch_rgb_tube_ly1(st, L, Q, G, depth, mode, 0, stats, queue)
+                                    : launch_rgb_tube_ly0(st, L, Q, G, depth, mode, 0, stats, queue);
+            if (name) return name;
+        }
         return launch_rgb_tile(st, L, P, G, depth, mode, stats, queue);
+    }
     // A ragged width on aligned (padded) rows: the fast kernel takes the columns up to the last multiple of
     // its unit, the scalar kernel the few that remain (each pixel is independent, so any split is exact).
     const int wv = G.w / pxt * pxt;

@@ -107,10 +107,37 @@ __global__ __launch_bounds__(256) void k_packed_generic(LutConsts L, PackedSet P
 
 static inline bool mult4(long long v) { return (v & 3) == 0; }
 
+// launches under this many pixels stay on the plain vector kernel (no start-up cost); LUTR_SMALL_JOB_MPX as in lutr_kernels.hip
+static bool small_job_packed(long long px)
+{
+    long long mpx = 70;
+    if (const char *e = getenv("LUTR_SMALL_JOB_MPX")) { const long long v = atoll(e); if (v >= 0 && v <= 100000) mpx = v; }
+    return px < mpx * 1000000ll;
+}
+
 const char *launch_packed(hipStream_t st, int variant, const LutConsts &L, const PackedSet &P, const FrameGeom &G,
-                          int wide, int nc, int mode)
+                          int wide, int nc, int mode, unsigned *stats, unsigned *queue)
 {
     const long long px = (long long)G.w * G.rows * G.nframes;
+    // round 3: the tube kernels (lutr_rgb2.hip) for the component orders that keep R, G, B adjacent: R G B [x], B G R [x], x R G B, x B G R
+    if ((variant == VAR_VEC_LDS || (variant == VAR_AUTO && !small_job_packed(px))) && !getenv("LUTR_NO_RGB2") &&
+        !(getenv("LUTR_RGB2") && getenv("LUTR_RGB2")[0] == '0')) {
+        const bool fwd = P.go == P.ro + 1 && P.bo == P.go + 1, bwd = P.go == P.bo + 1 && P.ro == P.go + 1;
+        const int p0 = fwd ? P.ro : P.bo;
+        if ((fwd || bwd) && (nc == 4 ? p0 <= 1 : p0 == 0)) {
+            PlaneSet Q{};
+            for (int k = 0; k < 3; k++) { Q.s[k] = P.s; Q.d[k] = P.d; Q.ss[k] = P.ss; Q.ds[k] = P.ds; Q.sfs[k] = P.sfs; Q.dfs[k] = P.dfs; }
+            const int depth = wide ? 16 : 8, rev = bwd ? 1 : 0;
+            const char *name = nullptr;
+            if (nc == 3) name = wide ? launch_rgb_tube_ly3(st, L, Q, G, depth, mode, rev, stats, queue)
+                                     : launch_rgb_tube_ly2(st, L, Q, G, depth, mode, rev, stats, queue);
+            else if (!wide) name = p0 ? launch_rgb_tube_ly5(st, L, Q, G, depth, mode, rev, stats, queue)
+                                      : launch_rgb_tube_ly4(st, L, Q, G, depth, mode, rev, stats, queue);
+            else name = p0 ? launch_rgb_tube_ly7(st, L, Q, G, depth, mode, rev, stats, queue)
+                           : launch_rgb_tube_ly6(st, L, Q, G, depth, mode, rev, stats, queue);
+            if (name) return name;
+        }
+    }
     bool vec_ok = (mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL) &&
                   G.w % 4 == 0 && px / 4 < 0x7fffffffll && mult4((long long)(uintptr_t)P.s) &&
                   mult4((long long)(uintptr_t)P.d) && mult4(P.ss) && mult4(P.ds) &&

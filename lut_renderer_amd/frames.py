@@ -95,8 +95,10 @@ def uniform_rgb(w: int, h: int, depth: int = 10, k: int = 0) -> List[np.ndarray]
     return [rng.integers(0, m + 1, size=(h, w), dtype=np.int64).astype(_dtype(depth)) for _ in range(3)]
 
 
-def natural_rgb(w: int, h: int, depth: int = 10, k: int = 0, noise_sigma_10bit: float = 2.0) -> List[np.ndarray]:
-    """gbrp order (G, B, R): a grey-ish gradient with per-channel tint, patches and noise."""
+def natural_rgb(w: int, h: int, depth: int = 10, k: int = 0, noise_sigma_10bit: float = 2.0,
+                chroma_gain: float = 1.0) -> List[np.ndarray]:
+    """gbrp order (G, B, R): a grey-ish gradient with per-channel tint, patches and noise.  `chroma_gain` scales every
+    pixel's distance from its own grey value (3 = the "vivid" frames)."""
     rng = np.random.default_rng(SEED_BASE + k)
     m = (1 << depth) - 1
     base = _bilinear_field(rng, h, w, 0.10, 0.85)
@@ -108,6 +110,9 @@ def natural_rgb(w: int, h: int, depth: int = 10, k: int = 0, noise_sigma_10bit: 
         mask = np.clip((1.0 - np.maximum(np.abs(xx - px) / rx, np.abs(yy - py) / ry)) / 0.08, 0.0, 1.0)
         for c in chans:
             c += rng.uniform(-0.2, 0.2) * mask
+    if chroma_gain != 1.0:
+        grey = (chans[0] + chans[1] + chans[2]) / 3.0
+        chans = [grey + chroma_gain * (c - grey) for c in chans]
     sig = noise_sigma_10bit * float(1 << depth) / 1024.0
     return [np.clip(np.rint(np.clip(c, 0, 1) * m + rng.normal(0.0, sig, size=(h, w))), 0, m).astype(_dtype(depth))
             for c in chans]
@@ -144,6 +149,8 @@ def make_rgb(dist: str, w: int, h: int, depth: int, k: int = 0) -> List[np.ndarr
         return uniform_rgb(w, h, depth, k)
     if dist == "natural":
         return natural_rgb(w, h, depth, k)
+    if dist == "vivid":
+        return natural_rgb(w, h, depth, k, chroma_gain=3.0)
     if dist.startswith("noise"):
         return natural_rgb(w, h, depth, k, noise_sigma_10bit=_noise_sigma(dist))
     raise ValueError(f"unknown distribution '{dist}'")

@@ -61,7 +61,7 @@ def test_rgb_parity(engine, orc, cube_dir, variant, depth, lutname):
             want = orc.apply_rgb(lut.table, lut.scale, depth, mode, src)
             got = _to_np(engine.apply_rgb(_to_dev(src, engine), depth=depth, interp=mode), src[0].dtype)
             _assert_equal(got, want, f"rgb {variant} d{depth} {mode} {lutname}")
-            assert variant == "generic" or ("vec" in engine.last_kernel or "tile" in engine.last_kernel)
+            assert variant == "generic" or any(t in engine.last_kernel for t in ("vec", "tile", "tube"))
     engine.set_variant("auto")
 
 
@@ -377,7 +377,8 @@ def test_packed_rgb_parity(engine, orc, cube_dir, pix_fmt):
                     got = engine.apply_packed(dev, pix_fmt=pix_fmt, interp=mode).cpu().numpy()
                     got = got.view(np.uint16) if bits == 16 else got
                     _assert_equal([got], [want], f"packed {pix_fmt} {variant} {mode} {w}x{h} {lutname}")
-                    expect = "k_packed_vec" if (variant == "auto" and w == 128 and mode in MODES3) else "k_packed_generic"
+                    # auto: the round-3 tube kernel (16-byte aligned rows of whole units), scalar kernel otherwise
+                    expect = "k_rgb_tube" if (variant == "auto" and w == 128 and mode in MODES3) else "k_packed_generic"
                     assert engine.last_kernel.startswith(expect), engine.last_kernel
     engine.set_variant("auto")
 

@@ -243,3 +243,86 @@ def test_bench_four_rank_rehearsal_on_one_gpu():
     d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 4 and d["collective"]["world"] == 4 and d["collective"]["data_path_collectives"] == 0
     assert d["strong"]["rows_per_gpu"] == 540 and d["strong"]["value"] > 0 and d["config"]["precision"] == "strict"
+
+
+# ------------------------------------------------------------------ round-3 RGB tube kernels (lutr_rgb2.hip)
+MODES3 = ("nearest", "trilinear", "tetrahedral")
+
+
+def _rgb_frames(dist, w, h, depth, k):
+    if dist == "wild":            # codes above 2^depth - 1 in 16-bit containers: the coordinate table does not cover them
+        g = frames.natural_rgb(w, h, depth, k=k)
+        rng = np.random.default_rng(k)
+        for p in g:
+            p[rng.integers(0, h, 12), rng.integers(0, w, 12)] = rng.integers(1 << depth, 65536, 12)
+        return g
+    return frames.make_rgb(dist, w, h, depth, k=k)
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12, 16])
+@pytest.mark.parametrize("lutname", ["log709_33.cube", "log709_65.cube", "identity_17.cube", "random_9.cube", "domain_2.cube"])
+def test_planar_rgb_tube_kernels(engine, orc, cube_dir, depth, lutname, monkeypatch):
+    """gbrp / gbrp10le / gbrp12le / gbrp16le on the tube kernels: near-grey content (tube), saturated and uniform content
+    (the optimistic vote fails, gather body), out-of-range container values, lattices staged whole (9^3, 17^3), a 65^3 tube,
+    a lattice outside [0, 1] (clip kept), frame batches and row shards -- bit-exact against the oracle."""
+    monkeypatch.setenv("LUTR_RGB2", "all")          # the product's policy keeps 16-bit containers and trilinear on the round-1 kernel
+    lut = cube.read_cube(cube_dir / lutname)
+    engine.set_lut(lut)
+    engine.set_variant("vec_lds")
+    try:
+        for dist in ("natural", "vivid", "uniform") + (("wild",) if depth in (10, 12) else ()):
+            src = _rgb_frames(dist, 256, 40, depth, 61)
+            for mode in MODES3:
+                want = orc.apply_rgb(lut.table, lut.scale, depth, mode, src)
+                dev = _to_dev(src, engine.device)
+                engine.tile_stats(True)
+                got = engine.apply_rgb(dev, depth=depth, interp=mode)
+                st = engine.tile_stats(False)
+                assert engine.last_kernel.startswith("k_rgb_tube<ly%d" % (0 if depth == 8 else 1)), engine.last_kernel
+                _assert_equal(_to_np(got, src[0].dtype), want, f"rgb tube d{depth} {mode} {lutname} {dist}")
+                assert st["tiles"] > 0 and st["tube_tiles"] + st["global_tiles"] == st["tiles"], st
+                if dist == "natural" and lutname == "log709_33.cube":
+                    assert st["tube_tiles"] >= 0.6 * st["tiles"], st
+                if lutname in ("identity_17.cube", "random_9.cube") and dist != "wild":
+                    assert "whole-lattice" in engine.last_kernel and st["global_tiles"] == 0, (engine.last_kernel, st)
+        # a batch, processed as two row shards
+        src = frames.natural_rgb(128, 50, depth, k=62)
+        want = orc.apply_rgb(lut.table, lut.scale, depth, "tetrahedral", src)
+        batch = [t.unsqueeze(0).repeat(3, 1, 1).contiguous() for t in _to_dev(src, engine.device)]
+        out = [torch.zeros_like(t) for t in batch]
+        engine.apply_rgb(batch, out, depth=depth, row0=0, rows=17)
+        engine.apply_rgb(batch, out, depth=depth, row0=17, rows=33)
+        for f in range(3):
+            _assert_equal(_to_np([t[f] for t in out], src[0].dtype), want, f"rgb tube batch shard d{depth} frame {f}")
+    finally:
+        engine.set_variant("auto")
+
+
+@pytest.mark.parametrize("pix_fmt", ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr", "rgb48le", "bgr48le",
+                                     "rgba64le", "bgra64le"])
+def test_packed_rgb_tube_kernels(engine, orc, cube_dir, pix_fmt):
+    """Every packed order that keeps R, G, B adjacent, on the tube kernels: blue-first orders run with permuted strides and
+    R / B swapped at staging, the fourth component is carried over, in place works."""
+    bits, nc = orc.PACKED[pix_fmt][:2]
+    depth = bits
+    for lutname in ("log709_33.cube", "random_9.cube"):
+        lut = cube.read_cube(cube_dir / lutname)
+        engine.set_lut(lut)
+        for dist in ("natural", "uniform"):
+            g, b, r = frames.make_rgb(dist, 256, 24, depth, k=63)
+            ro, go, bo = orc.PACKED[pix_fmt][2:5]
+            rng = np.random.default_rng(5)
+            img = rng.integers(0, 1 << bits, size=(24, 256, nc), dtype=g.dtype)        # alpha / padding: random, must survive
+            img[..., ro], img[..., go], img[..., bo] = r, g, b
+            dev = torch.from_numpy(img.view(np.int16) if bits == 16 else img).to(engine.device)
+            for mode in MODES3:
+                want = orc.apply_packed(lut.table, lut.scale, pix_fmt, mode, img)
+                got = engine.apply_packed(dev, pix_fmt=pix_fmt, interp=mode)
+                assert engine.last_kernel.startswith("k_rgb_tube"), engine.last_kernel
+                got = got.cpu().numpy()
+                _assert_equal([got.view(np.uint16) if bits == 16 else got], [want], f"packed tube {pix_fmt} {mode} {lutname} {dist}")
+            work = dev.clone()
+            engine.apply_packed(work, work, pix_fmt=pix_fmt, interp="tetrahedral")
+            want = orc.apply_packed(lut.table, lut.scale, pix_fmt, "tetrahedral", img)
+            got = work.cpu().numpy()
+            _assert_equal([got.view(np.uint16) if bits == 16 else got], [want], f"packed tube in place {pix_fmt}")
