@@ -562,7 +562,8 @@ def main():
                     job.apply(eng, s2, d2, mode)
                     st = eng.tile_stats(False)
                     extra[key][prec] = {"Mpx_s": round(nf_x * w * h / k2 / 1e6, 1), "kernel": eng.last_kernel,
-                                        "tiles": st["tiles"], "tube_tiles": st["tube_tiles"], "level2_tiles": st["level2_tiles"],
+                                        "tiles": st["tiles"], "tube_tiles": st["tube_tiles"], "mixed_tiles": st["mixed_tiles"],
+                                        "level2_tiles": st["level2_tiles"],
                                         "window_misses": st["misses"], "gather_tiles": st["global_tiles"],
                                         "windows_staged": st["staged"]}
                     log(f"[extra] {key:14s} {prec:6s} {extra[key][prec]}")

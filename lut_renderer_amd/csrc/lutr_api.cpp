@@ -354,7 +354,8 @@ int lutr_ctx_tile_stats(lutr_ctx *c, int enable, uint64_t out[8])
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(h, c->stats, sizeof(h), hipMemcpyDeviceToHost));
             for (int i = 0; i < 4; i++) out[i] = h[i];
-            out[4] = out[5] = 0;                                    // (round 1 reported a clock and wave lifetimes here)
+            out[4] = h[30];                                         // mixed tiles: tube body + gather body for the few lanes outside the tube
+            out[5] = 0;
             out[6] = h[12];                                         // tiles served by the workgroup's grey tube
             out[7] = h[6];                                          // tiles that needed the second-level (exact) window test
             if (getenv("LUTR_DEBUG"))

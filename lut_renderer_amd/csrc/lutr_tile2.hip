@@ -74,6 +74,9 @@
                                   // so the tube's cross-section is a near-square in the chroma plane; b - r = 2.12 cb - 1.80 cr makes it a
                                   // parallelogram stretched along the magenta-green diagonal and thin along orange-blue, where video lives
 #endif
+#ifndef LUTR_T2_MIXED
+#define LUTR_T2_MIXED 1           // mixed tiles (see the vote in k_yuv_tile2)
+#endif
 #ifndef LUTR_T2_NODE16
 #define LUTR_T2_NODE16 0          // 1: strict 4-tap kernels stage float4 nodes (one ds_read_b128 per tap, 4 LDS cycles) instead of 12-byte ones (ds_read2_b32 + ds_read_b32, 6 cycles)
 #endif
@@ -167,6 +170,7 @@ struct Geom {
                           // need no window at all; the per-wave windows serve the saturated rest.
     int tube_plane;       // nodes from one r plane of the tube to the next: (2 tube_h + 3)^2 plus a few nodes of padding chosen by the
                           // launcher so that cells one step apart on any two axes never share an LDS bank (tube_plane_stride)
+    int mix_max;          // a tile with at most this many lanes outside the tube runs as a MIXED tile (tube body + gather for the outliers)
     float tube_t;         // the test: |gv - rv| and |bu - rv| (RGB codes, chroma only) must stay <= tube_t over the lane's unit
     unsigned tube_rlo, tube_rhi;   // a raw chroma interval [lo, hi] (packed like the window boxes) that implies the test for both planes:
                                    // four saturating subtractions instead of ~35 VALU for the tiles that fit it (tube_rlo > tube_rhi: none)
@@ -577,7 +581,7 @@ DEV bool tube_holds(const YuvConsts &K, const Geom &TG, const Ext &e)
     const float dg0 = gv0 - rv1, dg1 = gv1 - rv0;
     const float db0 = LUTR_T2_TUBE_BG ? bu0 - gv1 : bu0 - rv1, db1 = LUTR_T2_TUBE_BG ? bu1 - gv0 : bu1 - rv0;
     const float worst = vmax3(fmaxf(-dg0, dg1), -db0, db1);
-    return __all(worst <= TG.tube_t);
+    return worst <= TG.tube_t;          // per lane: the caller votes
 }
 
 // The same bound sample by sample, for units with at most four chroma samples (4:2:0 and 4:2:2 at 10 bit): a pixel's chroma IS one
@@ -599,7 +603,7 @@ DEV bool tube_holds_samples(const YuvConsts &K, const Geom &TG, const TileIn<WIN
         const float rv = K.krv * crd, gv = fma_(K.kgu, cbd, K.kgv * crd), bu = K.kbu * cbd;
         worst = vmax3(worst, fabsf(gv - rv), fabsf(LUTR_T2_TUBE_BG ? bu - gv : bu - rv));
     }
-    return __all(worst <= TG.tube_t);
+    return worst <= TG.tube_t;          // per lane: the caller votes
 }
 
 // ---------------------------------------------------------------- restage
@@ -1331,7 +1335,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     else { Wt.o_g = N::lds * tube_nb; Wt.o_r = N::lds * (TG.tube_plane - tube_nb - 1); }
     Wt.fr = (float)Wt.o_r; Wt.fg = (float)Wt.o_g; Wt.fb = (float)N::lds;
     Wt.fc = (float)(lds_base() + tube_off + N::lds * ((TG.tube_h + 1) * tube_nb + TG.tube_h + 1));
-    unsigned st_tube = 0;
+    unsigned st_tube = 0, st_mixed = 0;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     bool first = true;
     if (!claim_chunk(TG, lane, fr, sx, ry, rem, first)) return;
@@ -1441,7 +1445,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         TK(tk_wait)                  // ... and this is the wait for this tile's own loads
 #endif
         Ext e = extremes<WIN, WOUT, CSX, CSY>(in);             // without the luma minimum: see below
-        bool use_tube = false;
+        bool use_tube = false, mixed = false, lane_in = true;
         if (TG.tube_h > 0) {
             // level 0: the tile's chroma keeps it inside the workgroup's grey tube (and its raw codes are legal for the clamp-free body)
             const uint32_t top = pack_hi<WIN>(TG.max_raw);
@@ -1455,12 +1459,18 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
                 // sigma = 16 frames +9 %, natural -0.8 %, 3 x chroma -1.5 %); the fast kernels' 8-cell tube gains 1.7 % there and loses
                 // 1.4 % on 3 x chroma: corner form
                 if constexpr (T::NC <= 4 && V != V_FAST && LUTR_T2_TUBE_SAMPLES)
-                    use_tube = tube_holds_samples<WIN, WOUT, CSX, CSY, PRE>(K, TG, in);
-                else use_tube = tube_holds<WIN, PRE>(K, TG, e);
+                    lane_in = tube_holds_samples<WIN, WOUT, CSX, CSY, PRE>(K, TG, in);
+                else lane_in = tube_holds<WIN, PRE>(K, TG, e);
+                use_tube = __all(lane_in);
+                // MIXED tile: a few lanes outside the tube (sensor noise: one outlier unit in 64 sends a whole tile away).  Every
+                // lane runs the tube body -- an outlier reads wherever its numbers point, LDS reads cannot fault -- and the
+                // outliers alone run the gather body afterwards, under a divergent branch: its instructions issue once for the
+                // wave, its memory requests (what a gather costs) shrink to those lanes.
+                if (!use_tube && LUTR_T2_MIXED) mixed = __popcll(__ballot(!lane_in)) <= TG.mix_max;
             }
         }
-        bool use_lds = use_tube;
-        if (!use_tube && !TG.whole) {
+        bool use_lds = use_tube || mixed;
+        if (!use_lds && !TG.whole) {
             e.ymin = luma_min<WIN, WOUT, CSX, CSY>(in);
             use_lds = box_holds(scratch_off, e);               // first level: raw extremes against the window's raw box
         }
@@ -1473,6 +1483,8 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             use_lds = __all((pk_subsat_vs(e.ymax, top) | pk_subsat_vs(e.cbmax, top) | pk_subsat_vs(e.crmax, top)) == 0u);
         } else if (use_tube) {
             st_tube++;
+        } else if (mixed) {
+            st_mixed++;
         } else if (use_lds) {
 #ifdef LUTR_T2_DEBUG_STATS
             if (l2run > 0 && lane == 0) atomicAdd(&TG.stats[21 + (l2run <= 1 ? 0 : l2run <= 2 ? 1 : l2run <= 4 ? 2 : l2run <= 8 ? 3 : l2run <= 16 ? 4 : 5)], (unsigned)l2run);
@@ -1537,7 +1549,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             for (int k = 0; k < T::CWO; k++) { out.cb[k] = in.cb[k % T::CWI]; out.cr[k] = in.cr[k % T::CWI]; }
         } else
         if (use_lds) {
-            tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, use_tube ? Wt : W, TG, in, out); TK(tk_body)
+            tile_body<true, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, (use_tube || mixed) ? Wt : W, TG, in, out); TK(tk_body)
             if constexpr (LUTR_T2_EXP >= 5) {      // the body again, EXP - 4 times, on inputs the compiler cannot tell are the same
 #pragma unroll 1
                 for (int rep = 0; rep < LUTR_T2_EXP - 4; rep++) {
@@ -1546,7 +1558,10 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
                 }
             }
         }
-        else { tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out); T2_COUNT(8); TK(tk_gath) }
+        if (!use_lds || (mixed && !lane_in)) {       // whole tiles (wave-uniform) or the outliers of a mixed tile (divergent)
+            tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out); TK(tk_gath)
+        }
+        if (!use_lds) T2_COUNT(8);
         {
             // Idle lanes of edge tiles processed a duplicate of a valid unit of this tile (load_tile clamps), so they
             // store the same bytes to the same place as its owner: no branch, fixed store count.
@@ -1570,7 +1585,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     if (TG.stats && lane == 0) {
         atomicAdd(&TG.stats[0], st_tiles); atomicAdd(&TG.stats[1], cnt[1]);
         atomicAdd(&TG.stats[2], cnt[8]); atomicAdd(&TG.stats[3], cnt[9]); atomicAdd(&TG.stats[6], cnt[0]);
-        atomicAdd(&TG.stats[12], st_tube);
+        atomicAdd(&TG.stats[12], st_tube); atomicAdd(&TG.stats[30], st_mixed);
     }
 }
 
@@ -1760,6 +1775,11 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
             h--;
         }
     }
+    // 63: whenever at least one lane is inside the tube.  Measured (64 UHD frames, strict | fast Gpx/s, profiles/r03_exp7_mixed_tiles.txt):
+    // sigma-16 frames 286 | 359 without mixed tiles, 342 | 399 at 16 lanes, 402 | 495 at 63; three times the chroma 337 | 391 -> 362 | 432.
+    // A tile with all 64 lanes outside goes to the wave's window as before.
+    tg.mix_max = 63;
+    if (const char *e = getenv("LUTR_MIX_MAX")) { const int c = atoi(e); if (c >= 0 && c <= 63) tg.mix_max = c; }
     tg.tube_rlo = 0xffffffffu; tg.tube_rhi = 0u;
     if (tg.tube_h > 0) {
         // the square |cb' - coff|, |cr' - coff| <= R (after the prologue) inside the tube's chroma region: both differences are linear in

@@ -252,7 +252,7 @@ class LutEngine:
         out = (C.c_uint64 * 8)()
         _native.check(self._lib.lutr_ctx_tile_stats(self._ctx, int(enable), out))
         return {"tiles": out[0], "misses": out[1], "global_tiles": out[2], "staged": out[3],
-                "tube_tiles": out[6], "level2_tiles": out[7]}
+                "tube_tiles": out[6], "level2_tiles": out[7], "mixed_tiles": out[4]}
 
     def sync(self) -> None:
         _native.check(self._lib.lutr_ctx_sync(self._ctx))
