@@ -677,23 +677,21 @@ DEV bool rebox(const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext
 // pay the second level).  Returns false (W untouched; the caller runs the global-gather body for this tile) when the
 // tile's colours do not fit a window, or a raw code lies above 2^din - 1.
 // Plane stride of a window: the smallest stride >= `nodes` for which cells one step apart on any axes never share an LDS bank
-// (see tube_plane_stride in the launcher: node index = pr * A + pg * B + pb, collision when dr A + dg B + db = 0 mod 32).
+// (see tube_plane_stride in the launcher: node index = pr * A + pg * B + pb, collision when dr A + dg B + db = 0 mod 32, i.e.
+// when A mod 32 lies within one of 0, +B or -B).  kGoodA[B mod 32] has bit (A mod 32) set for the strides that are fine; a
+// rotate and a find-first-set pick the padding -- this runs in every restage, and every wave starts with one (a search loop
+// here cost a short launch 30 us).
+__constant__ unsigned kGoodA[32] = {
+    0x00000000u, 0x00000000u, 0x1ffffff0u, 0x0fffffe0u, 0x47ffffc4u, 0x63ffff8cu, 0x71ffff1cu, 0x78fffe3cu, 0x7c7ffc7cu, 0x7e3ff8fcu,
+    0x7f1ff1fcu, 0x7f8fe3fcu, 0x7fc7c7fcu, 0x7fe38ffcu, 0x7ff11ffcu, 0x7ff83ffcu, 0x7ffc7ffcu, 0x7ff83ffcu, 0x7ff11ffcu, 0x7fe38ffcu,
+    0x7fc7c7fcu, 0x7f8fe3fcu, 0x7f1ff1fcu, 0x7e3ff8fcu, 0x7c7ffc7cu, 0x78fffe3cu, 0x71ffff1cu, 0x63ffff8cu, 0x47ffffc4u, 0x0fffffe0u,
+    0x1ffffff0u, 0x00000000u};
 DEV int win_plane_stride(int nodes, int nb)
 {
-    const int B = LUTR_T2_TUBE_BG ? nb - 1 : nb;
-#pragma unroll 1
-    for (int pad = 0; pad < 8; pad++) {
-        const int sr = nodes + pad, A = LUTR_T2_TUBE_BG ? sr - nb : sr - nb - 1;
-        bool bad = false;
-#pragma unroll 1
-        for (int k = 1; k < 27 && !bad; k++) {                   // (dr, dg, db) in {-1, 0, 1}^3 up to sign: k and 26 - k are opposite
-            const int dr = k % 3 - 1, dg = (k / 3) % 3 - 1, db = k / 9 - 1;
-            if (k == 13) continue;
-            bad = ((dr * A + dg * B + db) & 31) == 0;
-        }
-        if (!bad) return sr;
-    }
-    return nodes | 1;
+    const int B = LUTR_T2_TUBE_BG ? nb - 1 : nb, a0 = (LUTR_T2_TUBE_BG ? nodes - nb : nodes - nb - 1) & 31;
+    const unsigned m = kGoodA[B & 31];
+    const unsigned r = a0 ? (m >> a0) | (m << (32 - a0)) : m;           // bit k: padding k is fine
+    return r ? nodes + __builtin_ctz(r) : (nodes | 1);
 }
 
 template <int WIN, int INTERP, int PRE, int V>
@@ -1288,41 +1286,8 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         KB.ky = K.ky * 8.0f; KB.yb = K.yb * 8.0f;
         KB.krv = K.krv * 8.0f; KB.kgu = K.kgu * 8.0f; KB.kgv = K.kgv * 8.0f; KB.kbu = K.kbu * 8.0f;
     }
-    if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier ...
-    if (TG.whole) {                                                             // ... but for this one, in whole-lattice mode
-        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
-        const int nodes = L.n1 * L.n1 * L.n1;
-        for (int i = threadIdx.x; i < nodes; i += 64 * LUTR_T2_WPB) {
-            if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[i];
-            else {
-                const float4 v = L.lat[i];
-                if constexpr (N::lds == 16) ((float4 *)dst)[i] = v;
-                else { float *q = (float *)(dst + 12 * i); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
-            }
-        }
-        __syncthreads();
-    }
     const int tube_nb = 2 * TG.tube_h + 3;                    // nodes across each difference axis: cells -H..H, corners -H-1..H+1
     const int tube_nodes = TG.tube_h > 0 ? L.n1 * TG.tube_plane : 0;
-    if (TG.tube_h > 0) {
-        // node (ir, ig, ib) = lattice (r, g = r + ig - H - 1, b = g + ib - H - 1) [b = r + ib - H - 1 without LUTR_T2_TUBE_BG], clamped
-        // (a clamped node is never read by a valid pixel)
-        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
-        const int plane = TG.tube_plane, nmax = L.n1 - 1;
-        for (int i = threadIdx.x; i < tube_nodes; i += 64 * LUTR_T2_WPB) {
-            const int ir = i / plane, rem = i - ir * plane, ig = min(rem / tube_nb, tube_nb - 1), ib = rem - ig * tube_nb;   // (padding: any node)
-            const int gq = ir + ig - TG.tube_h - 1;
-            const int g = min(max(gq, 0), nmax), b = min(max((LUTR_T2_TUBE_BG ? gq : ir) + ib - TG.tube_h - 1, 0), nmax);
-            const int src = (ir * L.n1 + g) * L.n1 + b;
-            if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[src];
-            else {
-                const float4 v = L.lat[src];
-                if constexpr (N::lds == 16) ((float4 *)dst)[i] = v;
-                else { float *q = (float *)(dst + 12 * i); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
-            }
-        }
-        __syncthreads();
-    }
     const int lane = threadIdx.x & 63;
     const int wib = uni(threadIdx.x >> 6);
     const int tab_bytes = TG.tab_entries * 8;
@@ -1338,7 +1303,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     unsigned st_tube = 0, st_mixed = 0;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     bool first = true;
-    if (!claim_chunk(TG, lane, fr, sx, ry, rem, first)) return;
+    const bool have_work = claim_chunk(TG, lane, fr, sx, ry, rem, first);      // (no atomic: a wave's first chunk is its id)
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
@@ -1420,9 +1385,60 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
 #else
 #define TK(acc)
 #endif
-    TilePos np = pos_at(fr, sx, ry);          // the tile being fetched
+    // The first tile's loads go out BEFORE the workgroup stages its table and tube: a launch of a few frames would otherwise
+    // spend its first ~10 us with an idle memory system.
+    TilePos np = pos_at(have_work ? fr : 0, have_work ? sx : 0, have_work ? ry : 0);          // the tile being fetched
     TileIn<WIN, WOUT, CSX, CSY> nxt;
-    load_tile(nxt, np);
+    if (have_work) load_tile(nxt, np);
+    if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier ...
+    if (TG.whole) {                                                             // ... but for this one, in whole-lattice mode
+        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
+        const int nodes = L.n1 * L.n1 * L.n1;
+        for (int i = threadIdx.x; i < nodes; i += 64 * LUTR_T2_WPB) {
+            if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[i];
+            else {
+                const float4 v = L.lat[i];
+                if constexpr (N::lds == 16) ((float4 *)dst)[i] = v;
+                else { float *q = (float *)(dst + 12 * i); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
+            }
+        }
+        __syncthreads();
+    }
+    if (TG.tube_h > 0) {
+        // node (ir, ig, ib) = lattice (r, g = r + ig - H - 1, b = g + ib - H - 1) [b = r + ib - H - 1 without LUTR_T2_TUBE_BG], clamped
+        // (a clamped node is never read by a valid pixel)
+        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
+        const int plane = TG.tube_plane, nmax = L.n1 - 1;
+        // four nodes per thread in flight: the staging is a chain of L2 round trips, and a short launch pays it in full
+        constexpr int kSB = 4;
+        for (int base = threadIdx.x; base < tube_nodes; base += kSB * 64 * LUTR_T2_WPB) {
+            int src[kSB];
+#pragma unroll
+            for (int k = 0; k < kSB; k++) {
+                const int i = min(base + k * 64 * LUTR_T2_WPB, tube_nodes - 1);
+                const int ir = i / plane, rem = i - ir * plane, ig = min(rem / tube_nb, tube_nb - 1), ib = rem - ig * tube_nb;   // (padding: any node)
+                const int gq = ir + ig - TG.tube_h - 1;
+                const int g = min(max(gq, 0), nmax), b = min(max((LUTR_T2_TUBE_BG ? gq : ir) + ib - TG.tube_h - 1, 0), nmax);
+                src[k] = (ir * L.n1 + g) * L.n1 + b;
+            }
+            typename std::conditional<N::fast, uint2, float4>::type val[kSB];
+#pragma unroll
+            for (int k = 0; k < kSB; k++) {
+                if constexpr (N::fast) val[k] = L.lat16[src[k]];
+                else val[k] = L.lat[src[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < kSB; k++) {
+                const int i = min(base + k * 64 * LUTR_T2_WPB, tube_nodes - 1);      // (the last batch re-writes the final node: harmless)
+                if constexpr (N::fast) ((uint2 *)dst)[i] = val[k];
+                else if constexpr (N::lds == 16) ((float4 *)dst)[i] = val[k];
+                else { float *q = (float *)(dst + 12 * i); q[0] = val[k].x; q[1] = val[k].y; q[2] = val[k].z; }
+            }
+        }
+        __syncthreads();
+    }
+    if (!have_work) return;                   // (after the barriers above: every wave of the workgroup takes part in the staging)
+
     for (bool more = true; more;) {
         TileIn<WIN, WOUT, CSX, CSY> in = nxt;
         const TilePos cp = np;                // the tile being computed (its store pointers and clamps)
@@ -1605,17 +1621,19 @@ int device_cus()
     return cus;
 }
 
-void allow_lds(const void *kernel, size_t bytes)
+// false: the runtime refused 160 KB of dynamic LDS for this kernel (the launch would fail): the caller declines the call
+bool allow_lds(const void *kernel, size_t bytes)
 {
     static std::set<std::pair<int, const void *>> done;      // the attribute is per device
     static std::mutex mu;
-    if (bytes <= 65536) return;
+    if (bytes <= 65536) return true;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
-    if (done.count({dev, kernel})) return;
-    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (done.count({dev, kernel})) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
     done.insert({dev, kernel});
+    return true;
 }
 
 // Largest index (unsigned)(yy + {rv, gv, bu}) can take for raw codes in [0, 2^din - 1]: each sum is monotone in its inputs.
@@ -1671,11 +1689,23 @@ bool out_clip_dead(const YuvConsts &K, int chroma_n)
 #define LUTR_T2_ONLY 0      // 1: build the headline instance alone (development)
 #endif
 
+// The LUTR_* tuning knobs of this launcher (tools/ only) are read ONCE per process: round 2 called getenv a dozen times per
+// launch, which a stream of single-frame applies pays every time (bench.py host_us_per_apply).
+namespace {
+struct Knob {
+    const char *v;
+    explicit Knob(const char *name) : v(getenv(name)) {}
+    explicit operator bool() const { return v != nullptr; }
+    int num() const { return atoi(v); }
+};
+#define T2_KNOB(NAME) ([]() -> const Knob & { static const Knob k(NAME); return k; }())
+}  // namespace
+
 // Which variant serves this call?
 static int tile2_variant(const LutConsts &L, const YuvConsts &K, int lut_depth, int csx, int csy, bool fast)
 {
     const bool eq = L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2];
-    const bool tab = eq && lut_depth <= 10 && !getenv("LUTR_NO_TAB");
+    const bool tab = eq && lut_depth <= 10 && !T2_KNOB("LUTR_NO_TAB");
     const bool unit = L.unit && out_clip_dead(K, 1 << (csx + csy));
     if (fast && tab && unit && L.lat16) return t2::V_FAST;
     if (tab && unit) return t2::V_UNIT;
@@ -1714,12 +1744,12 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         const double eff = ((double)uw / (((uw + lw - 1) / lw) * lw)) * ((double)urows / (((urows + lh - 1) / lh) * lh));
         if (eff > best_eff + 0.02) { best_eff = eff; best = l; }
     }
-    if (const char *e = getenv("LUTR_LW_LOG2")) { const int c = atoi(e); if (c >= 2 && c <= 6) best = c; }
+    if (const Knob &e = T2_KNOB("LUTR_LW_LOG2")) { const int c = e.num(); if (c >= 2 && c <= 6) best = c; }
     tg.lw_log2 = best; tg.uw = uw; tg.urows = urows;
     tg.nsx = (uw + (1 << best) - 1) >> best;
     tg.nry = (urows + (64 >> best) - 1) / (64 >> best);
     int waves_per_cu = 16;
-    if (const char *e = getenv("LUTR_WAVES_PER_CU")) { const int c = atoi(e); if (c >= LUTR_T2_WPB && c <= 32 && c % LUTR_T2_WPB == 0) waves_per_cu = c; }
+    if (const Knob &e = T2_KNOB("LUTR_WAVES_PER_CU")) { const int c = e.num(); if (c >= LUTR_T2_WPB && c <= 32 && c % LUTR_T2_WPB == 0) waves_per_cu = c; }
     const int max_waves = device_cus() * waves_per_cu;
     int ch = 32 / (64 >> best);              // a chunk = 32 lane rows of a strip (64 px rows at 4:2:0): 16 tiles of 32 x 2 lanes, 8 of 16 x 4
     // ... and at least 8192 pixels: the queue is ONE counter, and 4096 waves get ~85 M atomic adds per second out of it (measured:
@@ -1728,7 +1758,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     const int tile_px = pxt * (1 << csy) * 64;
     if (ch * tile_px < 8192) ch = (8192 + tile_px - 1) / tile_px;
     if (ch < 1) ch = 1;
-    if (const char *e = getenv("LUTR_CHUNK")) { const int c = atoi(e); if (c >= 1 && c <= 256) ch = c; }
+    if (const Knob &e = T2_KNOB("LUTR_CHUNK")) { const int c = e.num(); if (c >= 1 && c <= 256) ch = c; }
     while (ch > 1 && (long long)G.nframes * tg.nsx * ((tg.nry + ch - 1) / ch) < max_waves / 4) ch >>= 1;
     tg.ch = ch; tg.nrc = (tg.nry + ch - 1) / ch; tg.nchunks = G.nframes * tg.nrc * tg.nsx;
     tg.tab_entries = vv >= V_TAB ? table_entries(K, din) : 0;
@@ -1738,7 +1768,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     const int lds_block = 163840 / blocks_per_cu - tg.tab_entries * 8 - 64 * LUTR_T2_WPB;
     // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
-    tg.whole = (blocks_per_cu == 1 && !getenv("LUTR_NO_WHOLE") && whole_bytes <= lds_block) ? 1 : 0;
+    tg.whole = (blocks_per_cu == 1 && !T2_KNOB("LUTR_NO_WHOLE") && whole_bytes <= lds_block) ? 1 : 0;
     // The grey tube (Geom::tube_h): all of r, |g - r| and |b - r| up to H cells.  Needs the table variants (equal channel scales: the
     // chroma-only bound of map_box), a blend (nearest rounds to a node, the bound is for floor), and room left for windows.
     // H: as wide as 70 % of the block's LDS allows while every wave keeps a window of 256 nodes, at most 8 cells of a 33^3 lattice
@@ -1749,12 +1779,12 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     tg.tube_h = 0; tg.tube_t = 0.0f; tg.tube_plane = 0;
     long long tube_bytes = 0;
     // (65^3: a tube that fits is 5 of ITS cells wide, +-20 8-bit codes -- 497 / 427 Gpx/s with it, 530 / 492 without: off above 40^3)
-    if (!tg.whole && vv >= V_TAB && mode != LUTR_INTERP_NEAREST && (L.n1 <= 41 || getenv("LUTR_TUBE_H"))) {
+    if (!tg.whole && vv >= V_TAB && mode != LUTR_INTERP_NEAREST && (L.n1 <= 41 || T2_KNOB("LUTR_TUBE_H"))) {
         int h = (8 * (L.n1 - 2) + 16) / 32;                       // 8 at 33^3
         // a short launch (under ~100 tiles per wave) does not earn back the ~8 us it takes to stage the widest tube: 5 cells there
         // (UHD, 8 / 16 / 32 / 64 frames per launch, Gpx/s at H = 8 | 5: 351 | 369, 445 | 456, 533 | 541, 598 | 595)
         if ((long long)G.nframes * tg.nsx * tg.nry < 100ll * max_waves) h = (5 * (L.n1 - 2) + 16) / 32;
-        if (const char *e = getenv("LUTR_TUBE_H")) h = atoi(e);
+        if (const Knob &e = T2_KNOB("LUTR_TUBE_H")) h = e.num();
         const float kappa = L.sc[0] * L.scale_f;
         const float eps = K.max_l * (1.0f / 2097152.0f) + 1e-3f;                 // as map_box
         const float slack = 1.0f + 2.0f * L.lut_max * (1.0f / 2097152.0f) + 2e-3f;
@@ -1762,10 +1792,10 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         // kernels' 12-byte nodes do not fit that at H = 7; they trade window size for tube width (H = 7, 16 windows of 139 nodes
         // instead of H = 6 / 277): natural +2 %, sigma-8 +0 %, sigma-16 +43 %, three times the chroma -7 % (profiles/r03_exp4.txt)
         int min_win = node == 12 ? 128 : 256, tube_pct = node == 12 ? 85 : 70;
-        if (const char *e = getenv("LUTR_MIN_WIN")) { const int c = atoi(e); if (c >= 128 && c <= 4096) min_win = c; }
-        if (const char *e = getenv("LUTR_TUBE_PCT")) { const int c = atoi(e); if (c >= 10 && c <= 95) tube_pct = c; }
+        if (const Knob &e = T2_KNOB("LUTR_MIN_WIN")) { const int c = e.num(); if (c >= 128 && c <= 4096) min_win = c; }
+        if (const Knob &e = T2_KNOB("LUTR_TUBE_PCT")) { const int c = e.num(); if (c >= 10 && c <= 95) tube_pct = c; }
         while (h >= 3) {
-            const long long nb = 2 * h + 3, plane = getenv("LUTR_TUBE_NOPAD") ? nb * nb : tube_plane_stride((int)nb);
+            const long long nb = 2 * h + 3, plane = T2_KNOB("LUTR_TUBE_NOPAD") ? nb * nb : tube_plane_stride((int)nb);
             const long long bytes = (long long)L.n1 * plane * node;
             const float t = ((float)(h + 1) - slack) / kappa - 1.0f - eps;
             if (bytes <= (long long)lds_block * tube_pct / 100 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= min_win && t > 0.0f) {
@@ -1779,7 +1809,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     // sigma-16 frames 286 | 359 without mixed tiles, 342 | 399 at 16 lanes, 402 | 495 at 63; three times the chroma 337 | 391 -> 362 | 432.
     // A tile with all 64 lanes outside goes to the wave's window as before.
     tg.mix_max = 63;
-    if (const char *e = getenv("LUTR_MIX_MAX")) { const int c = atoi(e); if (c >= 0 && c <= 63) tg.mix_max = c; }
+    if (const Knob &e = T2_KNOB("LUTR_MIX_MAX")) { const int c = e.num(); if (c >= 0 && c <= 63) tg.mix_max = c; }
     tg.tube_rlo = 0xffffffffu; tg.tube_rhi = 0u;
     if (tg.tube_h > 0) {
         // the square |cb' - coff|, |cr' - coff| <= R (after the prologue) inside the tube's chroma region: both differences are linear in
@@ -1787,11 +1817,19 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         const float s1 = fabsf(K.kgu) + fabsf(K.kgv - K.krv);
         const float s2 = LUTR_T2_TUBE_BG ? fabsf(K.kbu - K.kgu) + fabsf(K.kgv) : fabsf(K.kbu) + fabsf(K.krv);
         const float R = floorf(0.99f * tg.tube_t / fmaxf(s1, s2)) - 1.0f;
+        // (one entry of memory: a stream of applies repeats the same constants, and the scan is up to 65,536 codes long)
+        struct Memo { float pre, pc, pcb, pre_max, coff, R; int max_raw, lo, hi; };
+        static thread_local Memo memo = {0, 0, 0, 0, 0, -1.0f, -1, -1, -1};
         int lo = -1, hi = -1;
-        for (int raw = 0; raw <= tg.max_raw; raw++) {               // the prologue is a monotone map of raw codes
-            float c = (float)raw;
-            if (K.pre != 0.0f) c = fminf(fmaxf(floorf(fmaf(K.pc, c, K.pcb)), 0.0f), K.pre_max);
-            if (fabsf(c - K.coff) <= R) { if (lo < 0) lo = raw; hi = raw; }
+        if (memo.pre == K.pre && memo.pc == K.pc && memo.pcb == K.pcb && memo.pre_max == K.pre_max && memo.coff == K.coff &&
+            memo.R == R && memo.max_raw == tg.max_raw) { lo = memo.lo; hi = memo.hi; }
+        else {
+            for (int raw = 0; raw <= tg.max_raw; raw++) {           // the prologue is a monotone map of raw codes
+                float c = (float)raw;
+                if (K.pre != 0.0f) c = fminf(fmaxf(floorf(fmaf(K.pc, c, K.pcb)), 0.0f), K.pre_max);
+                if (fabsf(c - K.coff) <= R) { if (lo < 0) lo = raw; hi = raw; }
+            }
+            memo = Memo{K.pre, K.pc, K.pcb, K.pre_max, K.coff, R, tg.max_raw, lo, hi};
         }
         if (R >= 1.0f && lo >= 0) {
             auto rep = [&](unsigned v16) { return v16 | (v16 << 16); };
@@ -1800,7 +1838,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         }
     }
     int cap = (int)((lds_block - tube_bytes) / (node * LUTR_T2_WPB));
-    if (const char *e = getenv("LUTR_WIN_NODES")) { const int c = atoi(e); if (c >= 64 && c < cap) cap = c; }
+    if (const Knob &e = T2_KNOB("LUTR_WIN_NODES")) { const int c = e.num(); if (c >= 64 && c < cap) cap = c; }
     if (!tg.whole && cap < 128) return nullptr;
     tg.win_nodes = tg.whole ? 0 : cap;
     tg.queue = queue; tg.stats = stats;
@@ -1815,14 +1853,14 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         TP.ss[i] = (unsigned)P.ss[i]; TP.ds[i] = (unsigned)P.ds[i];
         TP.sfs[i] = (unsigned long long)P.sfs[i]; TP.dfs[i] = (unsigned long long)P.dfs[i];
     }
-    if (getenv("LUTR_DEBUG"))
+    if (T2_KNOB("LUTR_DEBUG"))
         fprintf(stderr, "[lutr t2] nsx %d nry %d chunk %d chunks %d blocks %u lds/block %zu win_nodes %d tab %d variant %d tube h %d plane %d t %.1f\n",
                 tg.nsx, tg.nry, tg.ch, tg.nchunks, grid.x, lds, tg.win_nodes, tg.tab_entries, vv, tg.tube_h, tg.tube_plane, tg.tube_t);
 
 #define T2_LAUNCH(WI, WO, X, Y, I, PR, VV, NAME) \
     do { \
         auto kern = k_yuv_tile2<WI, WO, X, Y, I, PR, VV>; \
-        allow_lds((const void *)kern, lds); \
+        if (!allow_lds((const void *)kern, lds)) return nullptr; \
         hipLaunchKernelGGL(kern, grid, block, lds, st, L, K, TP, G, tg); \
         return tg.whole ? NAME "+whole-lattice" : (tg.tube_h ? NAME "+tube" : NAME); \
     } while (0)
