@@ -231,7 +231,7 @@ static unsigned grid_for(long long units, unsigned cap = 0x7fffffffu)
 const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const PlaneSet &P,
                        const FrameGeom &G, int depth, int mode, unsigned *stats, unsigned *queue)
 {
-    if (L.pre && variant == VAR_VEC_LDS) variant = VAR_VEC_GLOBAL;     // a prelut: the tile kernels do not read one
+    // a prelut (.csp shaper): the round-3 tube kernels read one (three coordinate tables, 8- and 10-bit data); the round-1 tile kernel does not
     const bool tiles = L.pre == nullptr;
     const int wide = depth > 8;
     const int pxt = wide ? 8 : 16;
@@ -241,14 +241,14 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     for (int c = 0; c < 3 && vec_ok; c++)
         vec_ok = planes_aligned(P, c, 16, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
-    if (tiles && vec_ok && ((variant == VAR_AUTO && !small_job(px)) || variant == VAR_VEC_LDS)) {
+    if ((tiles || depth <= 10) && vec_ok && ((variant == VAR_AUTO && !small_job(px)) || variant == VAR_VEC_LDS)) {
         // round 3: the tube kernels (lutr_rgb2.hip) take the planes in (R, G, B) order; gbrp is (G, B, R)
         // Policy (profiles/r03_exp6*.txt): planar frames in 16-bit containers are memory-side and the round-1 kernel already moves
         // them at the box's copy rate (gbrp10le 5.2-5.4 TB/s); the tube kernel wins on 8-bit planes for the 4-tap modes
         // (gbrp tetrahedral 594 -> 637 Gpx/s).  LUTR_RGB2=all sends everything it can take to the tube kernels, =0 nothing.
         const char *pol = getenv("LUTR_RGB2");
         const bool all = pol && pol[0] == 'a', none = (pol && pol[0] == '0') || getenv("LUTR_NO_RGB2");
-        if (!none && (all || (!wide && mode != LUTR_INTERP_TRILINEAR))) {
+        if (!none && (all || !tiles || (mode != LUTR_INTERP_TRILINEAR && (!wide || depth > 12)))) {
             PlaneSet Q = P;
             const int from[3] = {2, 0, 1};
             for (int k = 0; k < 3; k++) {
@@ -259,8 +259,10 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
                                     : launch_rgb_tube_ly0(st, L, Q, G, depth, mode, 0, stats, queue);
             if (name) return name;
         }
-        return launch_rgb_tile(st, L, P, G, depth, mode, stats, queue);
+        if (tiles) return launch_rgb_tile(st, L, P, G, depth, mode, stats, queue);
+        if (variant == VAR_VEC_LDS) variant = VAR_VEC_GLOBAL;          // a prelut the tube kernels could not take (layout): vector kernels
     }
+    if (!tiles && variant == VAR_VEC_LDS) variant = VAR_VEC_GLOBAL;
     // A ragged width on aligned (padded) rows: the fast kernel takes the columns up to the last multiple of
     // its unit, the scalar kernel the few that remain (each pixel is independent, so any split is exact).
     const int wv = G.w / pxt * pxt;

@@ -85,6 +85,7 @@ struct Geom {
     int whole;            // the whole lattice is staged ((n+1)^3 nodes): no validity test
     int tube_h, tube_plane;
     int rev;              // memory order of the components is B, G, R: strides permuted, nodes staged with R and B swapped
+    int three;            // three coordinate tables (one per channel: a prelut, or DOMAIN scales that differ), else one
     unsigned *queue, *stats;
 };
 
@@ -190,6 +191,23 @@ DEV Crd crd_compute(const LutConsts &L, float code)
     const float s = fminf(x * L.sc[0], L.lut_max);       // codes and scales are >= 0: only the upper clip can bind
     Crd c;
     if constexpr (INTERP == LUTR_INTERP_NEAREST) {        // NEAR(x) = (int)(x + .5) with a double .5 (lutr_device.h near_f)
+        const float fl = floorf(s);
+        c.p = (s - fl >= .5f) ? fl + 1.0f : fl;
+        c.d = 0.0f;
+    } else { c.p = floorf(s); c.d = s - c.p; }
+    return c;
+}
+
+// coordinates of channel `ch` in the general case: a prelut (lut3d's 1D shaper, folded by the host into one lattice coordinate per
+// integer code and channel, LutConsts::pre) or per-channel DOMAIN scales
+template <int INTERP>
+DEV Crd crd_general(const LutConsts &L, int ch, float code)
+{
+    float s;
+    if (L.pre) s = L.pre[ch * L.pre_stride + min((int)code, L.pre_stride - 1)];
+    else s = fminf((code * L.scale_f) * L.sc[ch], L.lut_max);
+    Crd c;
+    if constexpr (INTERP == LUTR_INTERP_NEAREST) {
         const float fl = floorf(s);
         c.p = (s - fl >= .5f) ? fl + 1.0f : fl;
         c.d = 0.0f;
@@ -318,7 +336,7 @@ DEV Rgb3 px_blend(const LutConsts &L, const Prep &c, const Taps<INTERP> &T, bool
 // is symmetric.  They come out of the table's `prev` values, whatever the taps read.
 struct Acc { float amin, amax, bmin, bmax; };
 
-template <bool LDS, int LY, int INTERP, bool TAB, bool UNIT>
+template <bool LDS, int LY, int INTERP, int TAB, bool UNIT>
 DEV Acc tile_body(const LutConsts &L, const Addr &A, const Geom &TG, Unit<LY> &in, Unit<LY> &out)
 {
     using Y = Lay<LY>;
@@ -341,7 +359,12 @@ DEV Acc tile_body(const LutConsts &L, const Addr &A, const Geom &TG, Unit<LY> &i
                 const int i = g * GP + t, e = samp<LY>(i, k);
                 // the gather body also takes codes above 2^depth - 1 (16-bit containers), which the table does not cover and which
                 // lut3d does not clip before scaling: it computes its coordinates
-                if constexpr (TAB && LDS) q[t][k] = crd_table8(code8<Y::WIDE>(in.w[plane_of<LY>(k)], e, three));
+                if constexpr (TAB == 1 && LDS) q[t][k] = crd_table8(code8<Y::WIDE>(in.w[plane_of<LY>(k)], e, three));
+                else if constexpr (TAB == 3 && LDS) {
+                    // slot k's channel: planar frames arrive as (R, G, B), packed ones in memory order
+                    const unsigned tb = (unsigned)(swap ? 2 - k : k) * (unsigned)TG.tab_entries * 8u;
+                    q[t][k] = crd_table8(code8<Y::WIDE>(in.w[plane_of<LY>(k)], e, three) + tb);
+                } else if constexpr (TAB == 3) q[t][k] = crd_general<INTERP>(L, swap ? 2 - k : k, codef<Y::WIDE>(in.w[plane_of<LY>(k)], e));
                 else q[t][k] = crd_compute<INTERP>(L, codef<Y::WIDE>(in.w[plane_of<LY>(k)], e));
             }
         __builtin_amdgcn_sched_barrier(0);
@@ -415,7 +438,7 @@ DEV bool claim_chunk(const Geom &TG, int lane, int &fr, int &sx, int &ry, int &r
     return chunk_at(TG, c, fr, sx, ry, rem);
 }
 
-template <int LY, int INTERP, bool TAB, bool UNIT>
+template <int LY, int INTERP, int TAB, bool UNIT>
 __global__ __launch_bounds__(64 * LUTR_R2_WPB, 4)
 void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
 {
@@ -423,13 +446,19 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
     constexpr int NBL = NodeB<INTERP>::lds;
     const int lane = threadIdx.x & 63;
     // ---- LDS: [coordinate table][tube or whole lattice]
-    if constexpr (TAB) {
+    if constexpr (TAB == 1) {
         for (int q = threadIdx.x; q < TG.tab_entries; q += 64 * LUTR_R2_WPB) {
             const Crd c = crd_compute<INTERP>(L, fminf((float)q, L.maxf));
             *(float2 *)(smem + q * 8) = make_float2(c.p, c.d);
         }
+    } else if constexpr (TAB == 3) {
+        for (int q = threadIdx.x; q < 3 * TG.tab_entries; q += 64 * LUTR_R2_WPB) {
+            const int ch = q / TG.tab_entries, code = q - ch * TG.tab_entries;
+            const Crd c = crd_general<INTERP>(L, ch, (float)code);
+            *(float2 *)(smem + q * 8) = make_float2(c.p, c.d);
+        }
     }
-    const int lat_off = TG.tab_entries * 8;
+    const int lat_off = (TAB == 3 ? 3 : 1) * TG.tab_entries * 8;
     const int nb = 2 * TG.tube_h + 3;
     {
         char *dst = smem + lat_off;
@@ -513,7 +542,7 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
 
         // codes the table does not cover (10- / 12-bit data in 16-bit containers): the gather body clamps
         bool lane_ok = true;
-        if constexpr (TAB && Y::WIDE) {
+        if constexpr (TAB != 0 && Y::WIDE) {
             uint32_t acc = 0;
 #pragma unroll
             for (int p = 0; p < Y::NPL; p++)
@@ -626,14 +655,17 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     using namespace r2;
     constexpr int LY = LUTR_R2_LAYOUT;
     using Y = Lay<LY>;
-    if (!(L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2]) || L.pre) return nullptr;         // one coordinate table for the three channels
+    // one coordinate table serves the three channels unless the file has a prelut (.csp shaper) or DOMAIN scales that differ:
+    // then each channel gets its own (8- and 10-bit data; deeper containers compute their coordinates and take neither)
+    const bool three = !(L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2]) || L.pre != nullptr;
     if (mode != LUTR_INTERP_NEAREST && mode != LUTR_INTERP_TRILINEAR && mode != LUTR_INTERP_TETRAHEDRAL) return nullptr;
     if ((depth > 8) != (Y::WIDE != 0) || G.w % Y::PX) return nullptr;
     for (int p = 0; p < Y::NPL; p++)
         if (P.sfs[p] < 0 || P.dfs[p] < 0 || P.ss[p] <= 0 || P.ds[p] <= 0 || P.ss[p] >= (1 << 24) || P.ds[p] >= (1 << 24) ||
             ((uintptr_t)P.s[p] | (uintptr_t)P.d[p] | (uintptr_t)P.ss[p] | (uintptr_t)P.ds[p] | (uintptr_t)P.sfs[p] | (uintptr_t)P.dfs[p]) & 15)
             return nullptr;
-    const bool tab = depth <= 12;
+    const bool tab = three ? depth <= 10 : depth <= 12;
+    if (three && !tab) return nullptr;
     if (!Y::WIDE && !tab) return nullptr;
     Geom tg;
     const int uw = G.w / Y::PX;
@@ -658,8 +690,9 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.tab_entries = tab ? (1 << depth) : 0;
     tg.max_code = (1 << depth) - 1;
     tg.rev = rev;
+    tg.three = three ? 1 : 0;
     const int node = mode == LUTR_INTERP_TRILINEAR ? 16 : 12;
-    const long long room = 163840 - (long long)tg.tab_entries * 8;
+    const long long room = 163840 - (long long)(three ? 3 : 1) * tg.tab_entries * 8;
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
     tg.whole = whole_bytes <= room && !getenv("LUTR_NO_WHOLE");
     tg.tube_h = 0; tg.tube_plane = 0;
@@ -677,7 +710,7 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.queue = queue; tg.stats = stats;
     const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
     const dim3 grid((waves + LUTR_R2_WPB - 1) / LUTR_R2_WPB), block(64 * LUTR_R2_WPB);
-    const size_t lds = (size_t)tg.tab_entries * 8 + (size_t)lat_bytes;
+    const size_t lds = (size_t)(three ? 3 : 1) * tg.tab_entries * 8 + (size_t)lat_bytes;
     Planes TP;
     for (int i = 0; i < 3; i++) {
         const int p = i < Y::NPL ? i : 0;
@@ -705,13 +738,14 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     if (mode == I) { \
         if (tab) { \
             if constexpr (LY != LY_C3W && LY != LY_C4W0 && LY != LY_C4W1) { \
-                if (unit && I != 0) R2_LAUNCH(I, true, true, R2_NAME(I, ",tab,unit")); \
-                R2_LAUNCH(I, true, false, R2_NAME(I, ",tab")); \
+                if (three) R2_LAUNCH(I, 3, false, R2_NAME(I, ",tab3")); \
+                if (unit && I != 0) R2_LAUNCH(I, 1, true, R2_NAME(I, ",tab,unit")); \
+                R2_LAUNCH(I, 1, false, R2_NAME(I, ",tab")); \
             } \
         } else { \
             if constexpr (Y::WIDE) { \
-                if (unit && I != 0) R2_LAUNCH(I, false, true, R2_NAME(I, ",unit")); \
-                R2_LAUNCH(I, false, false, R2_NAME(I, "")); \
+                if (unit && I != 0) R2_LAUNCH(I, 0, true, R2_NAME(I, ",unit")); \
+                R2_LAUNCH(I, 0, false, R2_NAME(I, "")); \
             } \
         } \
     }

@@ -326,3 +326,46 @@ def test_packed_rgb_tube_kernels(engine, orc, cube_dir, pix_fmt):
             want = orc.apply_packed(lut.table, lut.scale, pix_fmt, "tetrahedral", img)
             got = work.cpu().numpy()
             _assert_equal([got.view(np.uint16) if bits == 16 else got], [want], f"packed tube in place {pix_fmt}")
+
+
+def test_prelut_and_per_channel_domains_on_the_tube_kernels(engine, orc, tmp_path, monkeypatch):
+    """VERDICT r2 missing #5: a cineSpace shaper (lut3d's prelut) on an LDS kernel.  The tube kernels give every channel its own
+    coordinate table (8- and 10-bit data), which also covers DOMAIN_MIN / DOMAIN_MAX that differ per channel; their vote runs on
+    the cells the tables deliver, so no analytic bound is needed.  Planar and packed, three modes, near-grey and uniform content."""
+    from tests.test_lut_formats import _csp_with_prelut
+    n = 17
+    tab = cube.log709_lattice(n)
+    xs = [np.array([0.0, 0.05, 0.2, 0.5, 0.8, 1.0]), np.linspace(0.0, 1.0, 33), np.array([0.0, 0.3, 0.6, 1.0])]
+    ys = [np.array([0.0, 0.2, 0.45, 0.7, 0.9, 1.0]), np.linspace(0.0, 1.0, 33) ** 0.6, np.array([0.0, 0.25, 0.7, 1.0])]
+    p = tmp_path / "shaped.csp"
+    _csp_with_prelut(p, n, tab, list(zip(xs, ys)))
+    q = cube.write_cube(tmp_path / "domains.cube", cube.log709_lattice(33), domain_min=(0.0, 0.0, 0.0), domain_max=(1.0, 1.6, 2.0))
+    monkeypatch.setenv("LUTR_RGB2", "all")      # (a LUT without a prelut keeps trilinear on the round-1 kernel under the default policy)
+    engine.set_variant("vec_lds")
+    try:
+        for path in (p, q):
+            lut = cube.read_lut(path)
+            n2, s2, t2, pre = orc.parse_lut_file_ex(path)
+            engine.set_lut(lut)
+            for depth in (8, 10):
+                dt = np.uint16 if depth > 8 else np.uint8
+                for dist in ("natural", "uniform"):
+                    rgb = frames.make_rgb(dist, 256, 40, depth, k=71)
+                    for mode in MODES3:
+                        got = engine.apply_rgb(_to_dev(rgb, engine.device), depth=depth, interp=mode)
+                        assert engine.last_kernel.startswith("k_rgb_tube") and "tab3" in engine.last_kernel, engine.last_kernel
+                        want = orc.apply_rgb(t2, s2, depth, mode, rgb, prelut=pre)
+                        _assert_equal(_to_np(got, dt), want, f"tab3 planar {path.name} d{depth} {mode} {dist}")
+            if pre is None:             # (the oracle's packed entry takes no prelut)
+                for pix_fmt in ("rgb24", "bgra", "argb"):
+                    bits, nc, ro, go, bo = orc.PACKED[pix_fmt]
+                    g, b, r = frames.make_rgb("natural", 256, 24, 8, k=72)
+                    img = np.zeros((24, 256, nc), np.uint8)
+                    img[..., ro], img[..., go], img[..., bo] = r, g, b
+                    for mode in MODES3:
+                        got = engine.apply_packed(torch.from_numpy(img).to(engine.device), pix_fmt=pix_fmt, interp=mode)
+                        assert "tab3" in engine.last_kernel, engine.last_kernel
+                        want = orc.apply_packed(t2, s2, pix_fmt, mode, img)
+                        _assert_equal([got.cpu().numpy()], [want], f"tab3 packed {pix_fmt} {mode}")
+    finally:
+        engine.set_variant("auto")
