@@ -77,6 +77,12 @@
 #ifndef LUTR_T2_MIXED
 #define LUTR_T2_MIXED 1           // mixed tiles (see the vote in k_yuv_tile2)
 #endif
+#ifndef LUTR_T2_WIN_BG
+#define LUTR_T2_WIN_BG LUTR_T2_TUBE_BG      // the per-wave windows' second difference axis (independent of the tube's)
+#endif
+#ifndef LUTR_T2_WIN_PAD
+#define LUTR_T2_WIN_PAD 1         // 1: window plane strides padded against LDS bank collisions (win_plane_stride), 0: round 2's `| 1`
+#endif
 #ifndef LUTR_T2_NODE16
 #define LUTR_T2_NODE16 0          // 1: strict 4-tap kernels stage float4 nodes (one ds_read_b128 per tap, 4 LDS cycles) instead of 12-byte ones (ds_read2_b32 + ds_read_b32, 6 cycles)
 #endif
@@ -452,14 +458,14 @@ DEV Cells map_box(const LutConsts &L, const YuvConsts &K, const Geom &TG, float 
     const float pb0 = cell_of<INTERP, PRE, V>(L, qclip(vb0, m), 2, te), pb1 = cell_of<INTERP, PRE, V>(L, qclip(vb1, m), 2, te);
     Cells c;
     c.r0 = (int)pr0; c.r1 = (int)pr1;
-    // the second difference axis is (b - g) [LUTR_T2_TUBE_BG] or (b - r)
+    // the second difference axis is (b - g) [LUTR_T2_WIN_BG] or (b - r)
     float g_lo = pg0 - pr1, g_hi = pg1 - pr0;                                                   // interval arithmetic
-    float b_lo = LUTR_T2_TUBE_BG ? pb0 - pg1 : pb0 - pr1, b_hi = LUTR_T2_TUBE_BG ? pb1 - pg0 : pb1 - pr0;
+    float b_lo = LUTR_T2_WIN_BG ? pb0 - pg1 : pb0 - pr1, b_hi = LUTR_T2_WIN_BG ? pb1 - pg0 : pb1 - pr0;
     if (L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2]) {
         // chroma-only difference terms at the corners that extremise them: gv - rv falls in cb and in cr;
         // bu - rv rises in cb and falls in cr; bu - gv rises in both (gv1 = gv at (cb0, cr0), gv0 = gv at (cb1, cr1))
         float dg0 = gv0 - rv1, dg1 = gv1 - rv0;
-        float db0 = LUTR_T2_TUBE_BG ? bu0 - gv1 : bu0 - rv1, db1 = LUTR_T2_TUBE_BG ? bu1 - gv0 : bu1 - rv0;
+        float db0 = LUTR_T2_WIN_BG ? bu0 - gv1 : bu0 - rv1, db1 = LUTR_T2_WIN_BG ? bu1 - gv0 : bu1 - rv0;
         const bool clips = vr0 < 0.0f || vg0 < 0.0f || vb0 < 0.0f || vr1 >= m + 1.0f || vg1 >= m + 1.0f || vb1 >= m + 1.0f;
         if (clips) { dg0 = fminf(dg0, 0.0f); dg1 = fmaxf(dg1, 0.0f); db0 = fminf(db0, 0.0f); db1 = fmaxf(db1, 0.0f); }
         const float kappa = L.sc[0] * L.scale_f;
@@ -524,7 +530,7 @@ DEV Bnd tile_bounds(const LutConsts &L, const YuvConsts &K, const Geom &TG, Tile
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-        for (int q = 0; q < NQ; q++) { hg[q] = pg_[q] - pr[q]; hb[q] = pb_[q] - (LUTR_T2_TUBE_BG ? pg_[q] : pr[q]); }
+        for (int q = 0; q < NQ; q++) { hg[q] = pg_[q] - pr[q]; hb[q] = pb_[q] - (LUTR_T2_WIN_BG ? pg_[q] : pr[q]); }
         if constexpr (T::BH * T::BW >= 2) {
 #pragma unroll
             for (int q = 0; q + 1 < T::BH * T::BW; q += 2) {
@@ -688,7 +694,8 @@ __constant__ unsigned kGoodA[32] = {
     0x1ffffff0u, 0x00000000u};
 DEV int win_plane_stride(int nodes, int nb)
 {
-    const int B = LUTR_T2_TUBE_BG ? nb - 1 : nb, a0 = (LUTR_T2_TUBE_BG ? nodes - nb : nodes - nb - 1) & 31;
+    const int B = LUTR_T2_WIN_BG ? nb - 1 : nb, a0 = (LUTR_T2_WIN_BG ? nodes - nb : nodes - nb - 1) & 31;
+    if (!LUTR_T2_WIN_PAD) return nodes | 1;
     const unsigned m = kGoodA[B & 31];
     const unsigned r = a0 ? (m >> a0) | (m << (32 - a0)) : m;           // bit k: padding k is fine
     return r ? nodes + __builtin_ctz(r) : (nodes | 1);
@@ -796,7 +803,7 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
             const int i = min(base + k * 64 + lane, total - 1);              // the last batch re-reads the final node: harmless
             const int ir = (int)(((float)i + 0.5f) * rcp_plane), rem = i - __mul24(ir, plane);
             const int ig = (int)(((float)rem + 0.5f) * rcp_nb), ib = rem - __mul24(ig, nb);
-            int r = r0 + ir, g = r + g0 + ig, b = (LUTR_T2_TUBE_BG ? g : r) + b0 + ib;
+            int r = r0 + ir, g = r + g0 + ig, b = (LUTR_T2_WIN_BG ? g : r) + b0 + ib;
             // nodes outside the cube are never referenced by a valid pixel: clamp to stay inside the lattice
             r = min(max(r, 0), nmax); g = min(max(g, 0), nmax); b = min(max(b, 0), nmax);
             const int src = __mul24(__mul24(r, n1) + g, n1) + b;
@@ -816,8 +823,8 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
         *(float4 *)(smem + scratch_off) = make_float4((float)wr0, (float)wg0, (float)wb0, (float)wr1);
         *(float2 *)(smem + scratch_off + 16) = make_float2((float)wg1, (float)wb1);
     }
-    // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pg-b0)     [(pb-pr-b0) without LUTR_T2_TUBE_BG]
-    if (LUTR_T2_TUBE_BG) { W.o_r = kLN * (sr - nb); W.o_g = kLN * (nb - 1); }
+    // node index = (pr-r0)*sr + (pg-pr-g0)*nb + (pb-pg-b0)     [(pb-pr-b0) without LUTR_T2_WIN_BG]
+    if (LUTR_T2_WIN_BG) { W.o_r = kLN * (sr - nb); W.o_g = kLN * (nb - 1); }
     else { W.o_r = kLN * (sr - nb - 1); W.o_g = kLN * nb; }
     W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)kLN;
     W.fc = (float)(lds_base() + slice_off - kLN * (r0 * sr + g0 * nb + b0));
@@ -1482,7 +1489,10 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
                 // lane runs the tube body -- an outlier reads wherever its numbers point, LDS reads cannot fault -- and the
                 // outliers alone run the gather body afterwards, under a divergent branch: its instructions issue once for the
                 // wave, its memory requests (what a gather costs) shrink to those lanes.
-                if (!use_tube && LUTR_T2_MIXED) mixed = __popcll(__ballot(!lane_in)) <= TG.mix_max;
+                // (strict kernels only: with a cheap restage -- win_plane_stride -- the fast kernels' H = 8 tube and 367-node windows do as
+                // well or better without it: three times the chroma 540 vs 518 Gpx/s, sigma-16 526 vs 539, profiles/r03_exp16_*.txt)
+                if constexpr (LUTR_T2_MIXED && V != V_FAST)
+                    if (!use_tube) mixed = __popcll(__ballot(!lane_in)) <= TG.mix_max;
             }
         }
         bool use_lds = use_tube || mixed;
@@ -1574,7 +1584,9 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
                 }
             }
         }
-        if (!use_lds || (mixed && !lane_in)) {       // whole tiles (wave-uniform) or the outliers of a mixed tile (divergent)
+        bool gather = !use_lds;                      // whole tiles (wave-uniform) ...
+        if constexpr (LUTR_T2_MIXED && V != V_FAST) gather = gather || (mixed && !lane_in);     // ... or the outliers of a mixed tile (divergent)
+        if (gather) {
             tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out); TK(tk_gath)
         }
         if (!use_lds) T2_COUNT(8);
@@ -1805,9 +1817,10 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
             h--;
         }
     }
-    // 63: whenever at least one lane is inside the tube.  Measured (64 UHD frames, strict | fast Gpx/s, profiles/r03_exp7_mixed_tiles.txt):
-    // sigma-16 frames 286 | 359 without mixed tiles, 342 | 399 at 16 lanes, 402 | 495 at 63; three times the chroma 337 | 391 -> 362 | 432.
-    // A tile with all 64 lanes outside goes to the wave's window as before.
+    // 63: whenever at least one lane is inside the tube; a tile with all 64 lanes outside goes to the wave's window as before.
+    // Measured for the strict kernels (64 UHD frames, Gpx/s, profiles/r03_exp16_mixed_tiles_cheap_restage.txt): sigma-16 frames
+    // 409 without mixed tiles, 423 / 426 / 428 / 435 at 8 / 16 / 32 / 63 lanes; sigma-8 498 -> 510; natural and saturated frames +-1 %.
+    // (profiles/r03_exp7_mixed_tiles.txt shows 286 -> 402: that build still paid 30 us of stride search per restage.)
     tg.mix_max = 63;
     if (const Knob &e = T2_KNOB("LUTR_MIX_MAX")) { const int c = e.num(); if (c >= 0 && c <= 63) tg.mix_max = c; }
     tg.tube_rlo = 0xffffffffu; tg.tube_rhi = 0u;

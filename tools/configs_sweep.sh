@@ -6,13 +6,14 @@ import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']; w=c.get('lds_window') or {}; o=d.get('other_precision') or {}
 wl=c['workload'].split(',')[0]
 chain=('pc->tv prologue + ' if c.get('range_src')=='pc' else '')+'lut3d'
-print('| %-32s | %2d^3 | %-11s | %-8s | %4d | %-22s | %-6s | %9.0f | %6.0f | %5.1f%% | %9s | %s | %s |' % (wl, c['lut_size'], c['interp'], c['distribution'], c['frames_per_gpu'], chain, c['precision'], d['value'], r['achieved'], 100*r['frac'], ('%.0f' % o['Mpx_s']) if o else '-', c['kernel'], '%d/%d/%d/%d/%d' % (w.get('tiles',0), w.get('tube_tiles',0), w.get('level2_tiles',0), w.get('misses',0), w.get('global_tiles',0))))"; }
-echo "| frames | LUT | interp | content | frames/step | chain | precision | Mpx/s | GB/s | of 8 TB/s | other precision Mpx/s | kernel | tiles/tube/level-2/restage attempts/gather |"
+print('| %-32s | %2d^3 | %-11s | %-8s | %4d | %-22s | %-6s | %9.0f | %6.0f | %5.1f%% | %9s | %s | %s |' % (wl, c['lut_size'], c['interp'], c['distribution'], c['frames_per_gpu'], chain, c['precision'], d['value'], r['achieved'], 100*r['frac'], ('%.0f' % o['Mpx_s']) if o else '-', c['kernel'], '%d/%d/%d/%d/%d/%d' % (w.get('tiles',0), w.get('tube_tiles',0), w.get('mixed_tiles',0), w.get('level2_tiles',0), w.get('misses',0), w.get('global_tiles',0))))"; }
+echo "| frames | LUT | interp | content | frames/step | chain | precision | Mpx/s | GB/s | of 8 TB/s | other precision Mpx/s | kernel | tiles/tube/mixed/level-2/restage attempts/gather |"
 echo "|---|---|---|---|---|---|---|---|---|---|---|---|---|"
 run --size uhd --fmt yuv420p10le --interp tetrahedral
 run --size uhd --fmt yuv420p10le --interp trilinear
 run --size uhd --fmt yuv420p10le --interp tetrahedral --dist noise8 --frames 64
 run --size uhd --fmt yuv420p10le --interp tetrahedral --dist noise16 --frames 64
+run --size uhd --fmt yuv420p10le --interp tetrahedral --dist vivid --frames 64
 run --size uhd --fmt yuv420p10le --interp tetrahedral --dist uniform --frames 64
 run --size uhd --fmt yuv420p10le --interp tetrahedral --lut 65
 run --size uhd --fmt yuv420p10le --interp tetrahedral --lut 17
@@ -32,7 +33,10 @@ run --size uhd --fmt gbrp10le --interp tetrahedral --frames 16
 run --size uhd --fmt gbrp10le --interp trilinear --frames 128
 run --size uhd --fmt gbrp --interp tetrahedral --frames 128
 run --size uhd --fmt gbrp10le --interp nearest --frames 128
-run --size uhd --fmt rgb24 --interp tetrahedral --frames 32
-run --size uhd --fmt rgba --interp tetrahedral --frames 32
-run --size uhd --fmt rgb48le --interp tetrahedral --frames 16
-run --size uhd --fmt rgba64le --interp tetrahedral --frames 16
+run --size uhd --fmt rgb24 --interp tetrahedral --frames 128
+run --size uhd --fmt rgba --interp tetrahedral --frames 128
+run --size uhd --fmt rgb48le --interp tetrahedral --frames 64
+run --size uhd --fmt rgba64le --interp tetrahedral --frames 64
+run --size uhd --fmt rgb24 --interp trilinear --frames 128
+run --size uhd --fmt bgra --interp tetrahedral --frames 128
+run --size uhd --fmt gbrp16le --interp tetrahedral --frames 64
