@@ -67,6 +67,82 @@ __global__ __launch_bounds__(256) void k_copy(const v4 *s, v4 *d, size_t n16)
     }
 }
 
+// one thread per 16 bytes, no loop: as many blocks as it takes (the shape of a plain elementwise kernel)
+template <int NT>
+__global__ __launch_bounds__(256) void k_copy1(const v4 *s, v4 *d, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) { v4 a = ld<NT>(s + i); a.x += 1u; st<NT>(d + i, a); }
+}
+// read only (three planes summed into one word per thread) and write only
+template <int NT>
+__global__ __launch_bounds__(256) void k_read(P6 P, size_t n16, unsigned *sink)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+#pragma unroll
+        for (int p = 0; p < 3; p++) { const v4 a = ld<NT>(P.s[p] + i); acc += a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x12345678u) *sink = acc;
+}
+template <int NT>
+__global__ __launch_bounds__(256) void k_write(P6 P, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+#pragma unroll
+        for (int p = 0; p < 3; p++) st<NT>(P.d[p] + i, v4{(unsigned)i, 1u, 2u, 3u});
+}
+
+// E4: the no-loop copy with the tile kernels' occupancy: 1024-thread workgroups that own the CU's whole LDS (one workgroup per CU,
+// 16 waves), each copying PER x 16 KB of the three planes and exiting
+template <int NT, int PER>
+__global__ __launch_bounds__(1024) void k_copy_wg(P6 P, size_t n16)
+{
+    extern __shared__ char lds_[];
+    if (threadIdx.x == 99999) lds_[0] = 1;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const size_t i = ((size_t)blockIdx.x * PER + j) * 1024 + threadIdx.x;
+        if (i < n16) {
+            v4 a[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) a[p] = ld<NT>(P.s[p] + i);
+#pragma unroll
+            for (int p = 0; p < 3; p++) { a[p].x += 1u; st<NT>(P.d[p] + i, a[p]); }
+        }
+    }
+}
+// E3: persistent, every wave owns ONE contiguous run of each plane (4096 sequential streams per plane)
+template <int NT>
+__global__ __launch_bounds__(1024) void k_runs(P6 P, size_t n16)
+{
+    const size_t waves = (size_t)gridDim.x * 16, w = (size_t)blockIdx.x * 16 + (threadIdx.x >> 6);
+    const size_t per = (n16 + waves - 1) / waves, lo = w * per, hi = lo + per < n16 ? lo + per : n16;
+    for (size_t i = lo + (threadIdx.x & 63); i < hi; i += 64) {
+        v4 a[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) a[p] = ld<NT>(P.s[p] + i);
+#pragma unroll
+        for (int p = 0; p < 3; p++) { a[p].x += 1u; st<NT>(P.d[p] + i, a[p]); }
+    }
+}
+// E1: the persistent grid-stride copy with every wave delayed by a pseudo-random time first (breaks the lock step of the waves)
+template <int NT>
+__global__ __launch_bounds__(256) void k_flat_jitter(P6 P, size_t n16)
+{
+    const unsigned h = (blockIdx.x * 2654435761u + (threadIdx.x >> 6) * 40503u) >> 20;       // 0 .. 4095
+    for (unsigned k = 0; k < (h & 1023u); k++) __builtin_amdgcn_s_sleep(8);
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+        v4 a[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) a[p] = ld<NT>(P.s[p] + i);
+#pragma unroll
+        for (int p = 0; p < 3; p++) { a[p].x += 1u; st<NT>(P.d[p] + i, a[p]); }
+    }
+}
+
 // ---------------------------------------------------------------- tile walker
 struct TG { int lw_log2, nsx, nry, ch, nrc, nchunks, row16, rows, frames; int stagger; unsigned *queue; size_t frame16; };
 
@@ -152,6 +228,38 @@ int main(int argc, char **argv)
     hipStream_t s = 0;
     auto report = [&](const char *name, double ms) { printf("%-64s %8.3f ms  %6.2f TB/s\n", name, ms, gb / ms); fflush(stdout); };
 
+    // the two directions alone, and the runtime's own device-to-device copy
+    {
+        const double gbh = 3.0 * plane / 1e9;
+        auto rep1 = [&](const char *name, double ms) { printf("%-64s %8.3f ms  %6.2f TB/s (one direction: %.2f GB)\n", name, ms, gbh / ms, gbh); fflush(stdout); };
+        rep1("read only, 3 planes, blocks 65536, plain", run_ms(s, 5, [&] { hipLaunchKernelGGL((k_read<0>), dim3(65536), dim3(256), 0, s, P, n16, queue); }));
+        rep1("read only, 3 planes, blocks 65536, nt", run_ms(s, 5, [&] { hipLaunchKernelGGL((k_read<1>), dim3(65536), dim3(256), 0, s, P, n16, queue); }));
+        rep1("write only, 3 planes, blocks 65536, plain", run_ms(s, 5, [&] { hipLaunchKernelGGL((k_write<0>), dim3(65536), dim3(256), 0, s, P, n16); }));
+        rep1("write only, 3 planes, blocks 65536, nt", run_ms(s, 5, [&] { hipLaunchKernelGGL((k_write<2>), dim3(65536), dim3(256), 0, s, P, n16); }));
+        report("hipMemcpyDtoDAsync x3 (the runtime's copy)", run_ms(s, 5, [&] { for (int p = 0; p < 3; p++) hipMemcpyDtoDAsync((hipDeviceptr_t)P.d[p], (hipDeviceptr_t)P.s[p], plane, s); }));
+        const unsigned nblk = (unsigned)((n16 + 255) / 256);
+        report("copy, one thread per 16 B (no loop) x3 launches, plain", run_ms(s, 5, [&] { for (int p = 0; p < 3; p++) hipLaunchKernelGGL((k_copy1<0>), dim3(nblk), dim3(256), 0, s, P.s[p], P.d[p], n16); }));
+        report("copy, one thread per 16 B (no loop) x3 launches, nt ld+st", run_ms(s, 5, [&] { for (int p = 0; p < 3; p++) hipLaunchKernelGGL((k_copy1<3>), dim3(nblk), dim3(256), 0, s, P.s[p], P.d[p], n16); }));
+    }
+    {
+        hipFuncSetAttribute((const void *)k_copy_wg<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)k_copy_wg<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)k_copy_wg<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)k_runs<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (size_t ldsb : {(size_t)0, (size_t)160 * 1024}) {
+            char nm[128];
+            snprintf(nm, sizeof nm, "3+3 no loop, 1024-thread blocks x 16 KB/plane, LDS %zu KB, nt st", ldsb / 1024);
+            report(nm, run_ms(s, 5, [&] { hipLaunchKernelGGL((k_copy_wg<2, 1>), dim3((unsigned)((n16 + 1023) / 1024)), dim3(1024), ldsb, s, P, n16); }));
+            snprintf(nm, sizeof nm, "3+3 short loop (4), 1024-thread blocks x 64 KB/plane, LDS %zu KB, nt st", ldsb / 1024);
+            report(nm, run_ms(s, 5, [&] { hipLaunchKernelGGL((k_copy_wg<2, 4>), dim3((unsigned)((n16 + 4095) / 4096)), dim3(1024), ldsb, s, P, n16); }));
+            snprintf(nm, sizeof nm, "3+3 short loop (16), 1024-thread blocks x 256 KB/plane, LDS %zu KB, nt st", ldsb / 1024);
+            report(nm, run_ms(s, 5, [&] { hipLaunchKernelGGL((k_copy_wg<2, 16>), dim3((unsigned)((n16 + 16383) / 16384)), dim3(1024), ldsb, s, P, n16); }));
+        }
+        report("3+3 persistent, one contiguous run per wave (256 x 16 waves), nt st", run_ms(s, 5, [&] { hipLaunchKernelGGL((k_runs<2>), dim3(256), dim3(1024), 160 * 1024, s, P, n16); }));
+        report("3+3 persistent, one contiguous run per wave (512 x 16 waves, no LDS), nt st", run_ms(s, 5, [&] { hipLaunchKernelGGL((k_runs<2>), dim3(512), dim3(1024), 0, s, P, n16); }));
+        report("flat 3+3 grid-stride, blocks 2048, waves jittered at start, nt st", run_ms(s, 5, [&] { hipLaunchKernelGGL((k_flat_jitter<2>), dim3(2048), dim3(256), 0, s, P, n16); }));
+        report("flat 3+3 grid-stride, blocks 1024 (16 waves/CU), jittered, nt st", run_ms(s, 5, [&] { hipLaunchKernelGGL((k_flat_jitter<2>), dim3(1024), dim3(256), 0, s, P, n16); }));
+    }
     // one big buffer pair (the guide's float4 copy), same bytes
     {
         // treat s0..s2 as one region if contiguous? not guaranteed: copy plane 0 -> plane 0 three times the size is not possible,
