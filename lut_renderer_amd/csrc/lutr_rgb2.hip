@@ -37,8 +37,11 @@
 #ifndef LUTR_R2_WPB
 #define LUTR_R2_WPB 16
 #endif
-#ifndef LUTR_R2_PER_LANE
-#define LUTR_R2_PER_LANE 1        // 1: lanes outside the tube run the gather body under a divergent branch; 0: the whole tile does
+#ifndef LUTR_R2_INPLACE
+#define LUTR_R2_INPLACE 0         // 1: results overwrite the unit's input words and the rare gather path re-reads its unit (12 words
+                                  // back, 4-pixel coordinate groups everywhere).  Parity green, but measured 2-9 % SLOWER than separate
+                                  // output words (gbrp 605 vs 637, gbrp16le 383 vs 422 Gpx/s relative to the same reference kernel):
+                                  // every write becomes a read-modify-write of a word whose other samples are still live input
 #endif
 #ifndef LUTR_R2_NT
 #define LUTR_R2_NT 1              // 1: non-temporal stores, 2: and loads
@@ -336,6 +339,8 @@ DEV Rgb3 px_blend(const LutConsts &L, const Prep &c, const Taps<INTERP> &T, bool
 // is symmetric.  They come out of the table's `prev` values, whatever the taps read.
 struct Acc { float amin, amax, bmin, bmax; };
 
+// `out` may be `in` itself (LUTR_R2_INPLACE): a pixel's three samples are read before they are written, every write preserves the
+// other samples of its word, and groups run in program order.
 template <bool LDS, int LY, int INTERP, int TAB, bool UNIT>
 DEV Acc tile_body(const LutConsts &L, const Addr &A, const Geom &TG, Unit<LY> &in, Unit<LY> &out)
 {
@@ -347,7 +352,7 @@ DEV Acc tile_body(const LutConsts &L, const Addr &A, const Geom &TG, Unit<LY> &i
     const bool swap = TG.rev != 0;
     // pixels whose coordinate reads are issued together: 4 where the registers allow (units of 8 words), else 2 -- a unit of 12
     // words in, 12 prefetched and 12 out leaves the tetrahedral body no room for 24 coordinates (one spilled register = scratch)
-    constexpr int GP = (Y::NPL * Y::NW >= 12 || Y::PX < 4) ? 2 : 4;
+    constexpr int GP = ((!LUTR_R2_INPLACE && Y::NPL * Y::NW >= 12) || (INTERP == LUTR_INTERP_TRILINEAR && Y::NW >= 12) || Y::PX < 4) ? 2 : 4;
     constexpr int TB = INTERP == LUTR_INTERP_TRILINEAR ? 1 : (INTERP == LUTR_INTERP_NEAREST ? GP : 2);   // pixels whose taps are in flight together
 #pragma unroll
     for (int g = 0; g < Y::PX / GP; g++) {
@@ -391,7 +396,7 @@ DEV Acc tile_body(const LutConsts &L, const Addr &A, const Geom &TG, Unit<LY> &i
             for (int t = 0; t < TB; t++) {
                 const int i = g * GP + tb + t;
                 const Rgb3 o = px_blend<LDS, INTERP, UNIT>(L, pc[t], tp[t], swap);
-                constexpr bool keep = Y::NC == 4;        // 4-component pixels: the output word starts as a copy of the input (alpha)
+                constexpr bool keep = Y::NC == 4 || LUTR_R2_INPLACE;   // the word holds alpha, or input samples still to be read
                 put<Y::WIDE, keep>(out.w[plane_of<LY>(0)], samp<LY>(i, 0), o.c0);
                 put<Y::WIDE, keep>(out.w[plane_of<LY>(1)], samp<LY>(i, 1), o.c1);
                 put<Y::WIDE, keep>(out.w[plane_of<LY>(2)], samp<LY>(i, 2), o.c2);
@@ -551,9 +556,13 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
             const uint32_t hi = ~(uint32_t)TG.max_code & 0xffffu;
             lane_ok = (acc & (hi | (hi << 16))) == 0u;
         }
+        st_tiles++;
+#if LUTR_R2_INPLACE
+        Unit<LY> &out = in;
+#else
         Unit<LY> out;
         if constexpr (Y::NC == 4) out = in;
-        st_tiles++;
+#endif
         {
             // optimistic pass for every lane (a lane with illegal codes or colours outside the tube reads wherever its numbers
             // point -- LDS reads cannot fault -- and its result is thrown away)
@@ -561,7 +570,6 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
             const float lim = (float)TG.tube_h;
             if (!TG.whole) lane_ok = lane_ok && acc.amin >= -lim && acc.amax <= lim && acc.bmin >= -lim && acc.bmax <= lim;
         }
-#if LUTR_R2_PER_LANE
         // Only the lanes that need it run the gather body (a divergent branch: the other lanes keep their result).  Its
         // instructions still issue once for the wave, but its memory requests -- what a gather costs -- shrink to those lanes:
         // a tile crossed by a saturated edge costs about two bodies instead of five.
@@ -569,18 +577,20 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
         else {
             st_gather++;
             if (!lane_ok) {
+#if LUTR_R2_INPLACE
+                // the optimistic pass has overwritten the unit: read it again (its own bytes: nothing has been stored over them yet,
+                // also when the caller works in place)
+                {
+                    const unsigned lxc = (unsigned)min(lx, cp.xlim), lyc = (unsigned)min(ly, cp.ylim);
+#pragma unroll
+                    for (int p = 0; p < Y::NPL; p++) ldw<Y::NW>(in.w[p], cp.s[p] + (__umul24(lyc, P.ss[p]) + lxc * UB));
+                }
+#else
                 if constexpr (Y::NC == 4) out = in;
+#endif
                 (void)tile_body<false, LY, INTERP, TAB, UNIT>(L, AG, TG, in, out);
             }
         }
-#else
-        if (__all(lane_ok)) st_tube++;
-        else {
-            if constexpr (Y::NC == 4) out = in;
-            (void)tile_body<false, LY, INTERP, TAB, UNIT>(L, AG, TG, in, out);
-            st_gather++;
-        }
-#endif
         {
             const unsigned lxc = (unsigned)min(lx, cp.xlim), lyc = (unsigned)min(ly, cp.ylim);
 #pragma unroll
