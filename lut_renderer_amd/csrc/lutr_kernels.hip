@@ -208,17 +208,19 @@ static bool planes_aligned(const PlaneSet &P, int plane, long long a, bool batch
     return true;
 }
 
-// The persistent tile kernels pay ~40 us before their first pixel is stored (coordinate table, tube staging) and end with a tail
-// of partly idle CUs, so they only win on big launches.  Round 2, Gpx/s tile / plain vector kernels (taps gathered from L1/L2,
-// 5-8 waves per SIMD; tools/small_sweep.sh): UHD yuv420p10le 1 frame 114 / 276, 4 frames 250 / 356, 8 frames 336 / 325,
-// 12 frames 386 / 329, 32 frames 524 / 334; 1080p 16 frames 251 / 356, 32 frames (66 Mpx) 340 / 322.  "auto" therefore sends
-// launches under 70 Mpx to the vector kernels.  LUTR_SMALL_JOB_MPX moves the boundary (0 = never).
-static bool small_job(long long px)
+// The persistent tile kernels pay a fixed start-up (coordinate table, tube staging, a wave's first tile at a quarter of the issue
+// rate) and end with a tail of partly idle CUs, so they only win on big launches.  Round 3, Gpx/s tile / plain vector kernels (taps
+// gathered from L1/L2, 5-8 waves per SIMD; profiles/r03_exp19_small_launches.txt), fused yuv420p10le strict: UHD 1 frame 181 / 272,
+// 2 frames 253 / 322, 4 frames 316 / 357, 8 frames 442 / 326, 16 frames 507 / 333, 64 frames 560 / 338; 1080p 8 frames 253 / 326,
+// 16 frames 337 / 300, 32 frames 424 / 324, 64 frames 478 / 329 -- the two-level chunk queue and its small chunks moved the
+// crossover of the fused kernels from 70 Mpx (round 2) to ~33 Mpx.  The RGB tile kernels keep 70 (their queue is round 1's).
+// LUTR_SMALL_JOB_MPX moves both boundaries (0 = never).
+static bool small_job(long long px, long long mpx = 70)
 {
-    long long mpx = 70;
     if (const char *e = getenv("LUTR_SMALL_JOB_MPX")) { const long long v = atoll(e); if (v >= 0 && v <= 100000) mpx = v; }
     return px < mpx * 1000000ll;
 }
+constexpr long long kSmallYuvMpx = 33;
 
 static unsigned grid_for(long long units, unsigned cap = 0x7fffffffu)
 {
@@ -241,7 +243,11 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     for (int c = 0; c < 3 && vec_ok; c++)
         vec_ok = planes_aligned(P, c, 16, G.nframes > 1);
     if (variant == VAR_GENERIC) vec_ok = false;
-    if ((tiles || depth <= 10) && vec_ok && ((variant == VAR_AUTO && !small_job(px)) || variant == VAR_VEC_LDS)) {
+    // which LDS kernel would take the launch decides where "small" ends: the tube kernels have the two-level queue (33 Mpx), round 1's kernel not (70)
+    const char *pol0 = getenv("LUTR_RGB2");
+    const bool tube_first = !((pol0 && pol0[0] == '0') || getenv("LUTR_NO_RGB2")) &&
+                            ((pol0 && pol0[0] == 'a') || !tiles || (mode != LUTR_INTERP_TRILINEAR && (!wide || depth > 12)));
+    if ((tiles || depth <= 10) && vec_ok && ((variant == VAR_AUTO && !small_job(px, tube_first ? kSmallYuvMpx : 70)) || variant == VAR_VEC_LDS)) {
         // round 3: the tube kernels (lutr_rgb2.hip) take the planes in (R, G, B) order; gbrp is (G, B, R)
         // Policy (profiles/r03_exp6*.txt): planar frames in 16-bit containers are memory-side and the round-1 kernel already moves
         // them at the box's copy rate (gbrp10le 5.2-5.4 TB/s); the tube kernel wins on 8-bit planes for the 4-tap modes
@@ -346,7 +352,7 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     const int pxt = win ? 8 : 16;
     const int bh = 1 << csy;
     if (L.pre && variant == VAR_VEC_LDS) variant = VAR_VEC_GLOBAL;     // a prelut: the tile kernels do not read one
-    if (variant == VAR_VEC_LDS || (variant == VAR_AUTO && !small_job((long long)G.w * G.rows * G.nframes))) {
+    if (variant == VAR_VEC_LDS || (variant == VAR_AUTO && !small_job((long long)G.w * G.rows * G.nframes, kSmallYuvMpx))) {
         if (const char *name = try_tile2(st, L, K, P, G, din, dout, lut_depth, csx, csy, mode, fast, stats, queue)) return name;
         if (variant == VAR_VEC_LDS) return nullptr;          // asked for the tile kernels, and they cannot take this call
     }
@@ -361,7 +367,7 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     // ragged width on aligned (padded) rows: tile kernel up to the last whole unit, scalar kernel for the rest
     // (the split falls on a chroma-block boundary: the unit is 8 or 16 luma samples wide)
     const int wv = G.w / pxt * pxt;
-    if (variant == VAR_AUTO && wv > 0 && wv < G.w && !small_job((long long)G.w * G.rows * G.nframes)) {
+    if (variant == VAR_AUTO && wv > 0 && wv < G.w && !small_job((long long)G.w * G.rows * G.nframes, kSmallYuvMpx)) {
         FrameGeom Gv = G, Ge = G;
         Gv.w = wv;
         Ge.w = G.w - wv;

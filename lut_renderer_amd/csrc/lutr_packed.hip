@@ -110,7 +110,7 @@ static inline bool mult4(long long v) { return (v & 3) == 0; }
 // launches under this many pixels stay on the plain vector kernel (no start-up cost); LUTR_SMALL_JOB_MPX as in lutr_kernels.hip
 static bool small_job_packed(long long px)
 {
-    long long mpx = 70;
+    long long mpx = 33;        // the tube kernels' crossover (two-level chunk queue): 8 UHD rgb24 frames run at 480 vs 343 Gpx/s
     if (const char *e = getenv("LUTR_SMALL_JOB_MPX")) { const long long v = atoll(e); if (v >= 0 && v <= 100000) mpx = v; }
     return px < mpx * 1000000ll;
 }

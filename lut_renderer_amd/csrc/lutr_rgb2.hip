@@ -430,16 +430,36 @@ DEV bool chunk_at(const Geom &TG, unsigned c, int &fr, int &sx, int &ry, int &re
     rem = min(TG.ch, TG.nry - ry);
     return true;
 }
-DEV bool claim_chunk(const Geom &TG, int lane, int &fr, int &sx, int &ry, int &rem, bool &first)
+// The two-level chunk queue of lutr_tile2.hip (claim_chunk there): a wave's first chunk is its id; after that it draws a ticket
+// from the workgroup's LDS counter, ticket 16 j + slot is chunk base[j] + slot, and the wave that draws slot 0 fetches
+// base[j] = atomicAdd(queue, 16) and publishes it.  LDS words at `wgq_off`: ticket at +0, base[8] at +32, ready[8] at +64.
+typedef __attribute__((address_space(3))) volatile unsigned *lds_vup;
+constexpr int kWgq = 128;
+DEV bool claim_chunk(const Geom &TG, int lane, int wgq_off, int &fr, int &sx, int &ry, int &rem, bool &first)
 {
     unsigned c = 0;
-    if (first) {
+    if (first) {          // (a wave whose id is not a chunk has no work: the counter starts behind the ids; runs before the LDS words are initialised)
         first = false;
         c = (unsigned)((int)(blockIdx.x * LUTR_R2_WPB) + uni((int)(threadIdx.x >> 6)));
-        if (c < (unsigned)TG.nchunks) return chunk_at(TG, c, fr, sx, ry, rem);
+        return chunk_at(TG, c, fr, sx, ry, rem);
     }
-    if (lane == 0) c = atomicAdd(TG.queue, 1u);
-    c = (unsigned)uni((int)c);
+    const lds_vup q = (lds_vup)(uintptr_t)(unsigned)(lds_base() + wgq_off);
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned *)q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t = (unsigned)uni((int)t);
+    const unsigned j = t >> 4, slot = t & 15u, r = j & 7u;
+    if (slot == 0) {
+        if (lane == 0) {
+            c = atomicAdd(TG.queue, 16u);
+            q[8 + r] = c;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            q[16 + r] = j + 1u;
+        }
+        c = (unsigned)uni((int)c);
+    } else {
+        while ((unsigned)uni((int)q[16 + r]) != j + 1u) __builtin_amdgcn_s_sleep(2);
+        c = (unsigned)uni((int)q[8 + r]) + slot;
+    }
     return chunk_at(TG, c, fr, sx, ry, rem);
 }
 
@@ -463,7 +483,9 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
             *(float2 *)(smem + q * 8) = make_float2(c.p, c.d);
         }
     }
-    const int lat_off = (TAB == 3 ? 3 : 1) * TG.tab_entries * 8;
+    const int wgq_off = (TAB == 3 ? 3 : 1) * TG.tab_entries * 8;                // the workgroup's chunk allocator (claim_chunk)
+    if (threadIdx.x < 24) ((unsigned *)(smem + wgq_off))[threadIdx.x + (threadIdx.x ? 7 : 0)] = 0u;
+    const int lat_off = wgq_off + kWgq;
     const int nb = 2 * TG.tube_h + 3;
     {
         char *dst = smem + lat_off;
@@ -502,7 +524,7 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
     }
     int fr, sx, ry, rem;
     bool first = true;
-    if (!claim_chunk(TG, lane, fr, sx, ry, rem, first)) return;
+    if (!claim_chunk(TG, lane, wgq_off, fr, sx, ry, rem, first)) return;
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     constexpr int UB = Y::NW * 4;                       // bytes of a unit per plane
@@ -540,7 +562,7 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
         const TilePos cp = np;
         if (--rem > 0) { ry++; pos_down(np); }
         else {
-            more = claim_chunk(TG, lane, fr, sx, ry, rem, first);
+            more = claim_chunk(TG, lane, wgq_off, fr, sx, ry, rem, first);
             if (more) np = pos_at(fr, sx, ry);
         }
         load_tile(nxt, np);
@@ -693,7 +715,10 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.nry = (G.rows + (64 >> best) - 1) / (64 >> best);
     const int max_waves = device_cus() * LUTR_R2_WPB;
     const int tile_px = Y::PX * 64;
-    int ch = (16384 + tile_px - 1) / tile_px;          // >= 8192 pixels per claim (the queue is one counter, lutr_tile2.hip); 16 K measured flat
+    // 4096 pixels per claim, 2048 when a wave gets fewer than 64 tiles (the two-level queue makes small chunks free, lutr_tile2.hip)
+    int ch = (4096 + tile_px - 1) / tile_px;
+    if ((long long)G.nframes * tg.nsx * tg.nry < 64ll * max_waves) ch = (2048 + tile_px - 1) / tile_px;
+    if (ch < 1) ch = 1;
     if (const char *e = getenv("LUTR_CHUNK")) { const int c = atoi(e); if (c >= 1 && c <= 256) ch = c; }
     while (ch > 1 && (long long)G.nframes * tg.nsx * ((tg.nry + ch - 1) / ch) < max_waves / 4) ch >>= 1;
     tg.ch = ch; tg.nrc = (tg.nry + ch - 1) / ch; tg.nchunks = G.nframes * tg.nrc * tg.nsx;
@@ -702,7 +727,7 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.rev = rev;
     tg.three = three ? 1 : 0;
     const int node = mode == LUTR_INTERP_TRILINEAR ? 16 : 12;
-    const long long room = 163840 - (long long)(three ? 3 : 1) * tg.tab_entries * 8;
+    const long long room = 163840 - (long long)(three ? 3 : 1) * tg.tab_entries * 8 - r2::kWgq;
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
     tg.whole = whole_bytes <= room && !getenv("LUTR_NO_WHOLE");
     tg.tube_h = 0; tg.tube_plane = 0;
@@ -720,7 +745,7 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.queue = queue; tg.stats = stats;
     const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
     const dim3 grid((waves + LUTR_R2_WPB - 1) / LUTR_R2_WPB), block(64 * LUTR_R2_WPB);
-    const size_t lds = (size_t)(three ? 3 : 1) * tg.tab_entries * 8 + (size_t)lat_bytes;
+    const size_t lds = (size_t)(three ? 3 : 1) * tg.tab_entries * 8 + kWgq + (size_t)lat_bytes;
     Planes TP;
     for (int i = 0; i < 3; i++) {
         const int p = i < Y::NPL ? i : 0;

@@ -95,6 +95,11 @@ namespace t2 {
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
+// LDS behind the coordinate table: 64 bytes of scratch per wave (window cell ranges, raw box, counters), then the WORKGROUP's
+// chunk allocator (claim_chunk): {ticket} at +0, base[8] at +32, ready[8] at +64.
+constexpr int kWaveScratch = LUTR_T2_WPB * 64;
+constexpr int kScratch = kWaveScratch + 128;
+
 enum { V_GEN = 0, V_TAB = 1, V_UNIT = 2, V_FAST = 3 };
 
 #define DEV __device__ __forceinline__
@@ -1248,17 +1253,49 @@ DEV bool chunk_at(const Geom &TG, unsigned c, int &fr, int &sx, int &ry, int &re
     return true;
 }
 
-// every wave takes its first chunk by its id (a burst of atomics on one address at kernel start serialises in the L2)
-DEV bool claim_chunk(const Geom &TG, int lane, int &fr, int &sx, int &ry, int &rem, bool &first)
+// Every wave takes its first chunk by its id (a burst of atomics on one address at kernel start serialises in the L2).  After
+// that chunks come from a TWO-LEVEL queue: a wave draws a ticket from its workgroup's LDS counter (a ds_add_rtn, ~100 cycles on the
+// lgkm counter, the vector-memory pipeline keeps running); ticket 16 j + slot means chunk base[j] + slot, and the wave that draws
+// slot 0 fetches base[j] = atomicAdd(queue, 16) for the block and publishes it in LDS (the others of that block, if they arrive
+// before it has landed, spin on the ready tag -- all waves of a workgroup are resident, the publisher cannot be descheduled).  One
+// claim in sixteen pays the L2 round trip that round 2 paid on every claim (its phase timers: 9 % of a wave's time, with the memory
+// pipeline drained behind it), and the global counter sees a sixteenth of the traffic, so short launches can use smaller chunks.
+#ifndef LUTR_T2_QUEUE2
+#define LUTR_T2_QUEUE2 1
+#endif
+typedef __attribute__((address_space(3))) volatile unsigned *lds_vup;
+DEV bool claim_chunk(const Geom &TG, int lane, int wgq_off, int &fr, int &sx, int &ry, int &rem, bool &first)
 {
     unsigned c = 0;
     if (first) {
+        // (a wave whose id is not a chunk has no work at all: the counter starts behind the ids.  It must not touch the
+        // allocator's LDS words either -- this call runs before they are initialised.)
         first = false;
         c = (unsigned)((int)(blockIdx.x * LUTR_T2_WPB) + uni((int)(threadIdx.x >> 6)));
-        if (c < (unsigned)TG.nchunks) return chunk_at(TG, c, fr, sx, ry, rem);
+        return chunk_at(TG, c, fr, sx, ry, rem);
     }
+#if LUTR_T2_QUEUE2
+    const lds_vup q = (lds_vup)(uintptr_t)(unsigned)(lds_base() + wgq_off);
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned *)q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t = (unsigned)uni((int)t);
+    const unsigned j = t >> 4, slot = t & 15u, r = j & 7u;
+    if (slot == 0) {
+        if (lane == 0) {
+            c = atomicAdd(TG.queue, 16u);
+            q[8 + r] = c;                                  // base[r]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            q[16 + r] = j + 1u;                            // ready[r]
+        }
+        c = (unsigned)uni((int)c);
+    } else {
+        while ((unsigned)uni((int)q[16 + r]) != j + 1u) __builtin_amdgcn_s_sleep(2);
+        c = (unsigned)uni((int)q[8 + r]) + slot;
+    }
+#else
     if (lane == 0) c = atomicAdd(TG.queue, 1u);
     c = (unsigned)uni((int)c);
+#endif
     return chunk_at(TG, c, fr, sx, ry, rem);
 }
 
@@ -1299,7 +1336,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     const int wib = uni(threadIdx.x >> 6);
     const int tab_bytes = TG.tab_entries * 8;
     const int scratch_off = tab_bytes + wib * 64;             // the window's cell ranges (second-level test)
-    const int tube_off = tab_bytes + LUTR_T2_WPB * 64;
+    const int tube_off = tab_bytes + kScratch;
     const int slice_off = tube_off + tube_nodes * N::lds + wib * TG.win_nodes * N::lds;
     Win Wt;                                                   // the tube as a window: same address form as a staged one
     // index = pr * plane + (pg - pr + H + 1) * nb + (pb - pg + H + 1)   [(pb - pr + H + 1) without LUTR_T2_TUBE_BG]
@@ -1310,7 +1347,9 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     unsigned st_tube = 0, st_mixed = 0;
     int fr, sx, ry, rem;                                      // the tile being fetched next
     bool first = true;
-    const bool have_work = claim_chunk(TG, lane, fr, sx, ry, rem, first);      // (no atomic: a wave's first chunk is its id)
+    const int wgq_off = tab_bytes + kWaveScratch;             // the workgroup's chunk allocator (claim_chunk)
+    if (threadIdx.x < 24) ((unsigned *)(smem + wgq_off))[threadIdx.x + (threadIdx.x ? 7 : 0)] = 0u;      // ticket, base[8], ready[8]
+    const bool have_work = claim_chunk(TG, lane, wgq_off, fr, sx, ry, rem, first);      // (no atomic: a wave's first chunk is its id)
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     const int cr0 = G.row0 >> CSY;                            // first unit row of this call's row range
@@ -1326,7 +1365,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         // lattice layout of the global copy ((N+1)^3 nodes, blue fastest, index N replicates N-1): prev + 1 is always staged
         W.o_r = N::lds * L.n1 * L.n1; W.o_g = N::lds * L.n1;
         W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)N::lds;
-        W.fc = (float)(lds_base() + tab_bytes + LUTR_T2_WPB * 64);
+        W.fc = (float)(lds_base() + tab_bytes + kScratch);
     }
     constexpr int YIB = T::YWI * 4, YOB = T::YWO * 4, CIB = T::CWI * 4, COB = T::CWO * 4;
 
@@ -1399,7 +1438,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     if (have_work) load_tile(nxt, np);
     if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier ...
     if (TG.whole) {                                                             // ... but for this one, in whole-lattice mode
-        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
+        char *dst = smem + TG.tab_entries * 8 + kScratch;
         const int nodes = L.n1 * L.n1 * L.n1;
         for (int i = threadIdx.x; i < nodes; i += 64 * LUTR_T2_WPB) {
             if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[i];
@@ -1414,7 +1453,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     if (TG.tube_h > 0) {
         // node (ir, ig, ib) = lattice (r, g = r + ig - H - 1, b = g + ib - H - 1) [b = r + ib - H - 1 without LUTR_T2_TUBE_BG], clamped
         // (a clamped node is never read by a valid pixel)
-        char *dst = smem + TG.tab_entries * 8 + LUTR_T2_WPB * 64;
+        char *dst = smem + TG.tab_entries * 8 + kScratch;
         const int plane = TG.tube_plane, nmax = L.n1 - 1;
         // four nodes per thread in flight: the staging is a chain of L2 round trips, and a short launch pays it in full
         constexpr int kSB = 4;
@@ -1444,6 +1483,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         }
         __syncthreads();
     }
+    __syncthreads();                          // (the allocator's LDS words are initialised; the general variant has no other barrier)
     if (!have_work) return;                   // (after the barriers above: every wave of the workgroup takes part in the staging)
 
     for (bool more = true; more;) {
@@ -1454,7 +1494,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         // fetched again, so every path has the same number of memory operations in flight.
         if (--rem > 0) { ry++; pos_down(np); }
         else {
-            more = claim_chunk(TG, lane, fr, sx, ry, rem, first);
+            more = claim_chunk(TG, lane, wgq_off, fr, sx, ry, rem, first);
             if (more) np = pos_at(fr, sx, ry);
         }
         load_tile(nxt, np);
@@ -1763,12 +1803,16 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     int waves_per_cu = 16;
     if (const Knob &e = T2_KNOB("LUTR_WAVES_PER_CU")) { const int c = e.num(); if (c >= LUTR_T2_WPB && c <= 32 && c % LUTR_T2_WPB == 0) waves_per_cu = c; }
     const int max_waves = device_cus() * waves_per_cu;
-    int ch = 32 / (64 >> best);              // a chunk = 32 lane rows of a strip (64 px rows at 4:2:0): 16 tiles of 32 x 2 lanes, 8 of 16 x 4
-    // ... and at least 8192 pixels: the queue is ONE counter, and 4096 waves get ~85 M atomic adds per second out of it (measured:
-    // UHD 10-bit throughput is exactly proportional to the chunk height up to 7 tiles -- 348 / 434 / 515 / 585 Gpx/s at 4 / 5 / 6 / 7 --
-    // and flat from 8: 648, 646 at 12)
+    // Chunk = `ch` consecutive tile rows of a strip.  Round 2's single counter capped the claim rate (4096 waves got ~85 M atomic adds
+    // per second out of it: UHD 10-bit throughput was proportional to the chunk height up to 7 tiles -- 348 / 434 / 515 / 585 Gpx/s at
+    // 4 / 5 / 6 / 7 -- and flat from 8), so chunks were at least 8192 pixels.  With the two-level queue (claim_chunk: one global atomic
+    // per 16 claims) small chunks are free -- 256 UHD frames at 8 / 4 / 2 tiles: 581 / 582 / 576 Gpx/s strict -- and they are what a
+    // short launch needs for its tail: 8 frames 347 / 361 / 436, 16 frames 438 / 490 / 501, 32 frames 518 / 535 / 536
+    // (profiles/r03_exp18_two_level_queue.txt).  4096 pixels per claim, 2048 when a wave gets fewer than 64 tiles.
     const int tile_px = pxt * (1 << csy) * 64;
-    if (ch * tile_px < 8192) ch = (8192 + tile_px - 1) / tile_px;
+    int ch = (4096 + tile_px - 1) / tile_px;
+    if ((long long)G.nframes * tg.nsx * tg.nry < 64ll * max_waves) ch = (2048 + tile_px - 1) / tile_px;
+    if (!LUTR_T2_QUEUE2) { ch = 32 / (64 >> best); if (ch * tile_px < 8192) ch = (8192 + tile_px - 1) / tile_px; }
     if (ch < 1) ch = 1;
     if (const Knob &e = T2_KNOB("LUTR_CHUNK")) { const int c = e.num(); if (c >= 1 && c <= 256) ch = c; }
     while (ch > 1 && (long long)G.nframes * tg.nsx * ((tg.nry + ch - 1) / ch) < max_waves / 4) ch >>= 1;
@@ -1777,7 +1821,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     tg.max_raw = (1 << din) - 1;
     const int node = vv == V_FAST ? 8 : ((mode == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
     const int blocks_per_cu = waves_per_cu / LUTR_T2_WPB > 0 ? waves_per_cu / LUTR_T2_WPB : 1;
-    const int lds_block = 163840 / blocks_per_cu - tg.tab_entries * 8 - 64 * LUTR_T2_WPB;
+    const int lds_block = 163840 / blocks_per_cu - tg.tab_entries * 8 - t2::kScratch;
     // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
     tg.whole = (blocks_per_cu == 1 && !T2_KNOB("LUTR_NO_WHOLE") && whole_bytes <= lds_block) ? 1 : 0;
@@ -1858,7 +1902,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
     const dim3 grid((waves + LUTR_T2_WPB - 1) / LUTR_T2_WPB), block(64 * LUTR_T2_WPB);
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_T2_WPB), 1, st) != hipSuccess) return nullptr;
-    const size_t lds = (size_t)tg.tab_entries * 8 + 64 * LUTR_T2_WPB +
+    const size_t lds = (size_t)tg.tab_entries * 8 + kScratch +
                        (tg.whole ? (size_t)whole_bytes : (size_t)tube_bytes + (size_t)LUTR_T2_WPB * tg.win_nodes * node);
     Planes2 TP;
     for (int i = 0; i < 3; i++) {
