@@ -246,15 +246,14 @@ const char *launch_rgb(hipStream_t st, int variant, const LutConsts &L, const Pl
     // which LDS kernel would take the launch decides where "small" ends: the tube kernels have the two-level queue (33 Mpx), round 1's kernel not (70)
     const char *pol0 = getenv("LUTR_RGB2");
     const bool tube_first = !((pol0 && pol0[0] == '0') || getenv("LUTR_NO_RGB2")) &&
-                            ((pol0 && pol0[0] == 'a') || !tiles || (mode != LUTR_INTERP_TRILINEAR && (!wide || depth > 12)));
+                            ((pol0 && pol0[0] == 'a') || !tiles || mode != LUTR_INTERP_TRILINEAR);
     if ((tiles || depth <= 10) && vec_ok && ((variant == VAR_AUTO && !small_job(px, tube_first ? kSmallYuvMpx : 70)) || variant == VAR_VEC_LDS)) {
         // round 3: the tube kernels (lutr_rgb2.hip) take the planes in (R, G, B) order; gbrp is (G, B, R)
-        // Policy (profiles/r03_exp6*.txt): planar frames in 16-bit containers are memory-side and the round-1 kernel already moves
-        // them at the box's copy rate (gbrp10le 5.2-5.4 TB/s); the tube kernel wins on 8-bit planes for the 4-tap modes
-        // (gbrp tetrahedral 594 -> 637 Gpx/s).  LUTR_RGB2=all sends everything it can take to the tube kernels, =0 nothing.
-        const char *pol = getenv("LUTR_RGB2");
-        const bool all = pol && pol[0] == 'a', none = (pol && pol[0] == '0') || getenv("LUTR_NO_RGB2");
-        if (!none && (all || !tiles || (mode != LUTR_INTERP_TRILINEAR && (!wide || depth > 12)))) {
+        // Policy (profiles/r03_exp21_planar_rgb_tube_vs_round1.txt): with the two-level chunk queue the tube kernel wins every 4-tap and
+        // nearest launch (gbrp10le tetrahedral 8 / 16 / 128 frames 359 / 412 / 432 vs 282 / 353 / 427 Gpx/s, gbrp 519 / 583 / 637 vs
+        // 379 / 447 / 593, gbrp nearest 885 = 0.66 of the peak); trilinear's eight 16-byte taps stay on round 1's kernel, which is
+        // 16-20 % faster there at 128 frames.  LUTR_RGB2=all sends everything it can take to the tube kernels, =0 nothing.
+        if (tube_first) {
             PlaneSet Q = P;
             const int from[3] = {2, 0, 1};
             for (int k = 0; k < 3; k++) {
