@@ -774,12 +774,12 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
         if (tab) { \
             if constexpr (LY != LY_C3W && LY != LY_C4W0 && LY != LY_C4W1) { \
                 if (three) R2_LAUNCH(I, 3, false, R2_NAME(I, ",tab3")); \
-                if (unit && I != 0) R2_LAUNCH(I, 1, true, R2_NAME(I, ",tab,unit")); \
+                if (unit) R2_LAUNCH(I, 1, true, R2_NAME(I, ",tab,unit")); \
                 R2_LAUNCH(I, 1, false, R2_NAME(I, ",tab")); \
             } \
         } else { \
             if constexpr (Y::WIDE) { \
-                if (unit && I != 0) R2_LAUNCH(I, 0, true, R2_NAME(I, ",unit")); \
+                if (unit) R2_LAUNCH(I, 0, true, R2_NAME(I, ",unit")); \
                 R2_LAUNCH(I, 0, false, R2_NAME(I, "")); \
             } \
         } \

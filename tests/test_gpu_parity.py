@@ -745,8 +745,8 @@ def test_contexts_on_concurrent_threads(orc, cube_dir):
 
 
 def test_small_jobs_take_the_low_latency_kernels(engine, orc, cube_dir, monkeypatch):
-    """Under "auto" a launch below the small-job boundary (70 Mpx by default) runs on the plain vector kernels
-    (3x lower latency for one 1080p frame), anything larger on the tile kernels; same pixels either way."""
+    """Under "auto" a launch below the small-job boundary (33 Mpx by default since round 3's two-level chunk queue) runs on the
+    plain vector kernels (lower latency for one frame), anything larger on the tile / tube kernels; same pixels either way."""
     lut = _load(engine, cube_dir, "log709_33.cube")
     src = frames.natural_yuv(512, 128, 10, 1, 1, k=5)
     rgb = frames.natural_rgb(512, 128, 10, k=5)
@@ -759,5 +759,5 @@ def test_small_jobs_take_the_low_latency_kernels(engine, orc, cube_dir, monkeypa
         assert engine.last_kernel.startswith(expect), engine.last_kernel
         _assert_equal(_to_np(got, np.uint16), want, f"small job boundary {mpx}")
         got = engine.apply_rgb(_to_dev(rgb, engine), depth=10)
-        assert engine.last_kernel.startswith(expect.replace("yuv", "rgb")), engine.last_kernel
+        assert engine.last_kernel.startswith("k_rgb_vec" if mpx == "95" else "k_rgb_tube"), engine.last_kernel
         _assert_equal(_to_np(got, np.uint16), want_rgb, f"small job boundary {mpx} rgb")

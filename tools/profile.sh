@@ -5,7 +5,7 @@
 # Pass 4: SQ counters.  Output: gpurun_out/prof_$TAG/...
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O; cd $R
 ARGS="--steps 12 --warmup 4 --lean --no-stats --no-other $@"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py $ARGS > $O/kt.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py $ARGS > $O/fetch.log 2>&1

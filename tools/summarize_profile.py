@@ -7,6 +7,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM
 WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Both raw and corrected values are kept."""
 import csv
 import glob
+import os
 import json
 import shutil
 import sys
@@ -18,12 +19,17 @@ src = Path("gpurun_out") / f"prof_{tag}"
 dst = Path("profiles")
 dst.mkdir(exist_ok=True)
 summary = {"tag": tag}
-for f in sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")))[-1:]:
+def newest(pattern):
+    """the most recently written match (gpurun merges every call's files into gpurun_out/: older runs of a tag stay beside the new one)"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+for f in newest(str(src / "kt" / "*" / "*_kernel_stats.csv")):
     shutil.copy(f, dst / f"{rnd}_{tag}_kernel_stats.csv")
     rows = list(csv.DictReader(open(f)))
     summary["kernel_stats"] = [{k: r[k][:120] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")}
                                for r in rows[:3]]
-for f in sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_trace.csv")))[-1:]:
+for f in newest(str(src / "kt" / "*" / "*_kernel_trace.csv")):
     rows = [r for r in csv.DictReader(open(f)) if "lutr::" in r["Kernel_Name"] and "make_lat16" not in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     summary["dispatch_us"] = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1) for r in rows]
@@ -38,7 +44,7 @@ if summary.get("kernel_stats"):
         main = max(cand, key=lambda k: float(k["Calls"]) * float(k["AverageNs"]))["Name"].split("(")[0]
 summary["kernel_stats"] = [k for k in summary.get("kernel_stats", [])]
 for sub in ("fetch", "write", "sq", "tcc"):
-    for f in sorted(glob.glob(str(src / sub / "*" / "*_counter_collection.csv")))[-1:]:
+    for f in newest(str(src / sub / "*" / "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if "lutr::" in r["Kernel_Name"] and (main is None or r["Kernel_Name"].startswith(main)):
                 kernel = r["Kernel_Name"].split("(")[0]
