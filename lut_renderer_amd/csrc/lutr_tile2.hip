@@ -83,6 +83,11 @@
 #ifndef LUTR_T2_WIN_PAD
 #define LUTR_T2_WIN_PAD 1         // 1: window plane strides padded against LDS bank collisions (win_plane_stride), 0: round 2's `| 1`
 #endif
+#ifndef LUTR_T2_PRIO
+#define LUTR_T2_PRIO 1            // s_setprio around the phases of a tile.  1: a wave between its body and the next one -- stores, chunk
+                                  // claim, the next tile's loads -- goes first, so memory operations leave as early as they can
+                                  // (strict 587-589 -> 593 Gpx/s, fast +0.1 %); 2: the body goes first (-1.7 %); 0: off
+#endif
 #ifndef LUTR_T2_NODE16
 #define LUTR_T2_NODE16 0          // 1: strict 4-tap kernels stage float4 nodes (one ds_read_b128 per tap, 4 LDS cycles) instead of 12-byte ones (ds_read2_b32 + ds_read_b32, 6 cycles)
 #endif
@@ -1498,6 +1503,11 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             if (more) np = pos_at(fr, sx, ry);
         }
         load_tile(nxt, np);
+#if LUTR_T2_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif LUTR_T2_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
 
 #ifndef LUTR_T2_EXP
 #define LUTR_T2_EXP 0             // timing experiments only (wrong pixels): 1 = trust the first window forever, 2 = + no stores, 3 = no body, 5.. = body repeated
@@ -1630,6 +1640,11 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out); TK(tk_gath)
         }
         if (!use_lds) T2_COUNT(8);
+#if LUTR_T2_PRIO == 1
+        __builtin_amdgcn_s_setprio(3);      // stores, the queue and the next tile's loads go first
+#elif LUTR_T2_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         {
             // Idle lanes of edge tiles processed a duplicate of a valid unit of this tile (load_tile clamps), so they
             // store the same bytes to the same place as its owner: no branch, fixed store count.
