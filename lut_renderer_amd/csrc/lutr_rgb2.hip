@@ -654,9 +654,11 @@ bool allow_lds(const void *kernel, size_t bytes)
     return true;
 }
 
-// see tube_plane_stride in lutr_tile2.hip: node index = pr * A + pg * B + pb, no collision mod 32 for steps of +-1 (+-2 if possible)
-int tube_plane_stride(int nb)
+// see tube_plane_stride in lutr_tile2.hip: node index = pr * A + pg * B + pb, no collision mod 32 (mod 16 for the 16-byte nodes of
+// trilinear, read with ds_read_b128) for steps of +-1 (+-2 if possible)
+int tube_plane_stride(int nb, int node)
 {
+    const int mod = node == 16 ? 16 : 32;
     int best = nb * nb, best_bad = 1 << 30;
     for (int pad = 0; pad < 12; pad++) {
         const int plane = nb * nb + pad, A = plane - nb, B = nb - 1;
@@ -665,13 +667,15 @@ int tube_plane_stride(int nb)
             for (int dg = -2; dg <= 2; dg++)
                 for (int db = -2; db <= 2; db++) {
                     if (!dr && !dg && !db) continue;
-                    if (((dr * A + dg * B + db) & 31) == 0) bad += (abs(dr) <= 1 && abs(dg) <= 1 && abs(db) <= 1) ? 100 : 1;
+                    if (((dr * A + dg * B + db) % mod + mod) % mod == 0) bad += (abs(dr) <= 1 && abs(dg) <= 1 && abs(db) <= 1) ? 100 : 1;
                 }
         if (bad < best_bad) { best_bad = bad; best = plane; }
         if (!bad) break;
     }
     return best;
 }
+// (17-node rows of 16-byte nodes collide on every g step whatever the plane stride; skipping H = 7 for H = 6 there measured WORSE --
+// gbrp trilinear 410 -> 379, rgb24 407 -> 369 Gpx/s: the wider tube is worth more than the conflicts cost)
 
 }  // namespace
 
@@ -736,7 +740,7 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
         int h = L.n1 - 2;                               // |differences| never exceed n - 1
         if (const char *e = getenv("LUTR_TUBE_H")) h = atoi(e);
         for (; h >= 2; h--) {
-            const int nb = 2 * h + 3, plane = tube_plane_stride(nb);
+            const int nb = 2 * h + 3, plane = tube_plane_stride(nb, node);
             const long long bytes = (long long)L.n1 * plane * node;
             if (bytes <= room) { tg.tube_h = h; tg.tube_plane = plane; lat_bytes = bytes; break; }
         }

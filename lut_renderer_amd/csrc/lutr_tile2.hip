@@ -702,12 +702,16 @@ __constant__ unsigned kGoodA[32] = {
     0x7f1ff1fcu, 0x7f8fe3fcu, 0x7fc7c7fcu, 0x7fe38ffcu, 0x7ff11ffcu, 0x7ff83ffcu, 0x7ffc7ffcu, 0x7ff83ffcu, 0x7ff11ffcu, 0x7fe38ffcu,
     0x7fc7c7fcu, 0x7f8fe3fcu, 0x7f1ff1fcu, 0x7e3ff8fcu, 0x7c7ffc7cu, 0x78fffe3cu, 0x71ffff1cu, 0x63ffff8cu, 0x47ffffc4u, 0x0fffffe0u,
     0x1ffffff0u, 0x00000000u};
+__constant__ unsigned short kGoodA16[16] = {      // the same for 16-byte nodes (ds_read_b128: indices collide mod 16)
+    0x0000u, 0x0000u, 0x1ff0u, 0x0fe0u, 0x47c4u, 0x638cu, 0x711cu, 0x783cu, 0x7c7cu, 0x783cu, 0x711cu, 0x638cu, 0x47c4u, 0x0fe0u, 0x1ff0u, 0x0000u};
+template <int NODE>
 DEV int win_plane_stride(int nodes, int nb)
 {
-    const int B = LUTR_T2_WIN_BG ? nb - 1 : nb, a0 = (LUTR_T2_WIN_BG ? nodes - nb : nodes - nb - 1) & 31;
     if (!LUTR_T2_WIN_PAD) return nodes | 1;
-    const unsigned m = kGoodA[B & 31];
-    const unsigned r = a0 ? (m >> a0) | (m << (32 - a0)) : m;           // bit k: padding k is fine
+    constexpr int M = NODE == 16 ? 16 : 32;
+    const int B = LUTR_T2_WIN_BG ? nb - 1 : nb, a0 = (LUTR_T2_WIN_BG ? nodes - nb : nodes - nb - 1) & (M - 1);
+    const unsigned m = NODE == 16 ? (unsigned)kGoodA16[B & 15] : kGoodA[B & 31];
+    const unsigned r = a0 ? ((m >> a0) | (m << (M - a0))) & (NODE == 16 ? 0xffffu : 0xffffffffu) : m;      // bit k: padding k is fine
     return r ? nodes + __builtin_ctz(r) : (nodes | 1);
 }
 
@@ -756,7 +760,7 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
         // odd row and plane strides: the nodes of neighbouring cells (the ones a wave reads together) differ by +-1, +-nb,
         // +-(sr - nb - 1) and small sums of those -- kept away from multiples of 16 nodes, i.e. from the same LDS banks
         const int nb_ = need_b | 1;
-        const int sr_ = win_plane_stride(need_g * nb_, nb_), nr_ = cap / sr_;
+        const int sr_ = win_plane_stride<kLN>(need_g * nb_, nb_), nr_ = cap / sr_;
         if (nr_ < need_r) continue;
         ng = need_g; nb = nb_; sr = sr_; nr = nr_;
         r0 = uni(c.r0) - ((nr - need_r) >> 1); g0 = uni(c.g0) - 1; b0 = uni(c.b0) - 1;
@@ -784,7 +788,7 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
         int spare = 1;
         for (;;) {                                   // one spare cell on each side of the chroma-like axes if it fits
             ng = need_g + 2 * spare; nb = (need_b + 2 * spare) | 1;
-            sr = win_plane_stride(ng * nb, nb);
+            sr = win_plane_stride<kLN>(ng * nb, nb);
             nr = cap / sr;
             if (nr >= need_r + 2 * spare || spare == 0) break;
             spare--;
@@ -1720,8 +1724,11 @@ int table_entries(const YuvConsts &K, int din)
 // read is 32 lanes per pass, the bank is the dword address mod 32 or 64, node strides of 2 or 3 dwords are invertible mod 32).
 // The unpadded 15 x 15 and 17 x 17 planes of the strict kernels' tubes have exactly that for (dr, dg) = +-(1, 1): every luma step
 // that moves r and g but not b costs a second LDS pass.  A few nodes of padding per plane remove it.
-int tube_plane_stride(int nb)
+int tube_plane_stride(int nb, int node)
 {
+    // 16-byte nodes are read with ds_read_b128: 16 lanes per pass, bank = dword address mod 64, a node is four dwords -- two lanes
+    // collide when their node indices agree mod 16 (not 32)
+    const int mod = node == 16 ? 16 : 32;
     int best = nb * nb, best_bad = 1 << 30;
     for (int pad = 0; pad < 12; pad++) {
         const int plane = nb * nb + pad;
@@ -1731,14 +1738,13 @@ int tube_plane_stride(int nb)
             for (int dg = -2; dg <= 2; dg++)
                 for (int db = -2; db <= 2; db++) {
                     if (!dr && !dg && !db) continue;
-                    if (((dr * A + dg * B + db) & 31) == 0) bad += (abs(dr) <= 1 && abs(dg) <= 1 && abs(db) <= 1) ? 100 : 1;
+                    if (((dr * A + dg * B + db) % mod + mod) % mod == 0) bad += (abs(dr) <= 1 && abs(dg) <= 1 && abs(db) <= 1) ? 100 : 1;
                 }
         if (bad < best_bad) { best_bad = bad; best = plane; }
         if (!bad) break;
     }
     return best;
 }
-
 bool out_clip_dead(const YuvConsts &K, int chroma_n)
 {
     const float m = K.max_l, mn = K.max_l * (float)chroma_n;
@@ -1866,7 +1872,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         if (const Knob &e = T2_KNOB("LUTR_MIN_WIN")) { const int c = e.num(); if (c >= 128 && c <= 4096) min_win = c; }
         if (const Knob &e = T2_KNOB("LUTR_TUBE_PCT")) { const int c = e.num(); if (c >= 10 && c <= 95) tube_pct = c; }
         while (h >= 3) {
-            const long long nb = 2 * h + 3, plane = T2_KNOB("LUTR_TUBE_NOPAD") ? nb * nb : tube_plane_stride((int)nb);
+            const long long nb = 2 * h + 3, plane = T2_KNOB("LUTR_TUBE_NOPAD") ? nb * nb : tube_plane_stride((int)nb, node);
             const long long bytes = (long long)L.n1 * plane * node;
             const float t = ((float)(h + 1) - slack) / kappa - 1.0f - eps;
             if (bytes <= (long long)lds_block * tube_pct / 100 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= min_win && t > 0.0f) {

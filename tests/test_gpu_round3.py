@@ -281,7 +281,7 @@ def test_planar_rgb_tube_kernels(engine, orc, cube_dir, depth, lutname, monkeypa
                 assert engine.last_kernel.startswith("k_rgb_tube<ly%d" % (0 if depth == 8 else 1)), engine.last_kernel
                 _assert_equal(_to_np(got, src[0].dtype), want, f"rgb tube d{depth} {mode} {lutname} {dist}")
                 assert st["tiles"] > 0 and st["tube_tiles"] + st["global_tiles"] == st["tiles"], st
-                if dist == "natural" and lutname == "log709_33.cube":
+                if dist == "natural" and lutname == "log709_33.cube" and mode != "trilinear":     # (trilinear's 16-byte nodes: a narrower tube)
                     assert st["tube_tiles"] >= 0.6 * st["tiles"], st
                 if lutname in ("identity_17.cube", "random_9.cube") and dist != "wild":
                     assert "whole-lattice" in engine.last_kernel and st["global_tiles"] == 0, (engine.last_kernel, st)
