@@ -231,7 +231,10 @@ struct Addr {
     int o0, o1, o2;               // byte steps of +1 along the slots
 };
 
-template <int INTERP> struct NodeB { static constexpr int lds = INTERP == LUTR_INTERP_TRILINEAR ? 16 : 12; };
+#ifndef LUTR_R2_TRI12
+#define LUTR_R2_TRI12 0           // 1: trilinear stages 12-byte nodes too (wider tube, 16 LDS reads per pixel instead of 8)
+#endif
+template <int INTERP> struct NodeB { static constexpr int lds = (INTERP == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) ? 16 : 12; };
 
 template <bool LDS, int NB> DEV f4 tap(const LutConsts &L, int a)
 {
@@ -730,7 +733,7 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.max_code = (1 << depth) - 1;
     tg.rev = rev;
     tg.three = three ? 1 : 0;
-    const int node = mode == LUTR_INTERP_TRILINEAR ? 16 : 12;
+    const int node = (mode == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) ? 16 : 12;
     const long long room = 163840 - (long long)(three ? 3 : 1) * tg.tab_entries * 8 - r2::kWgq;
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
     tg.whole = whole_bytes <= room && !getenv("LUTR_NO_WHOLE");
