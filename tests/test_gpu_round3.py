@@ -369,3 +369,10 @@ def test_prelut_and_per_channel_domains_on_the_tube_kernels(engine, orc, tmp_pat
                         _assert_equal([got.cpu().numpy()], [want], f"tab3 packed {pix_fmt} {mode}")
     finally:
         engine.set_variant("auto")
+
+
+def test_soak_rgb_tube_kernels_against_the_generic_kernel():
+    """tools/soak_rgb.py for a few seconds: random lattices, domains, formats, orders, modes, shards and content swept across the
+    tube's limit in every direction, the tube kernels against the scalar kernel sample by sample (a long run is in DESIGN.md 7)."""
+    res = subprocess.run([sys.executable, str(ROOT / "tools" / "soak_rgb.py"), "12"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "rgb soak ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
