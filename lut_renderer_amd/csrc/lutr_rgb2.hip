@@ -234,7 +234,14 @@ struct Addr {
 #ifndef LUTR_R2_TRI12
 #define LUTR_R2_TRI12 0           // 1: trilinear stages 12-byte nodes too (wider tube, 16 LDS reads per pixel instead of 8)
 #endif
-template <int INTERP> struct NodeB { static constexpr int lds = (INTERP == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) ? 16 : 12; };
+#ifndef LUTR_R2_NODE16
+#define LUTR_R2_NODE16 0          // 1: the 4-tap modes stage float4 nodes too (one ds_read_b128 per tap, 4 LDS cycles instead of 6; tube H = 7
+                                  // instead of 8 at 33^3): rgb24 608 vs 618, gbrp 646 vs 649, sigma-16 frames -5 % (profiles/r03_exp25): the
+                                  // LDS is not what these kernels wait for
+#endif
+template <int INTERP> struct NodeB {
+    static constexpr int lds = ((INTERP == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) || (INTERP != LUTR_INTERP_TRILINEAR && LUTR_R2_NODE16)) ? 16 : 12;
+};
 
 template <bool LDS, int NB> DEV f4 tap(const LutConsts &L, int a)
 {
@@ -708,10 +715,13 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     if (!Y::WIDE && !tab) return nullptr;
     Geom tg;
     const int uw = G.w / Y::PX;
-    // lanes across x: 32 (x 2 rows) unless another shape wastes 2 % fewer lanes at the frame's edges
-    int best = 5;
+    // lanes across x: 32 (x 2 rows) for the 16-bit containers (memory side: long runs), 8 (x 8 rows) for the 8-bit ones (VALU side:
+    // compact tiles see fewer colours and pass the vote more often -- rgb24 617 / 609 / 569, rgba 562 / 561 / 550 Gpx/s at 8 / 16 / 32
+    // lanes, gbrp10le 425 / 442 / 462, profiles/r03_exp27) -- unless another shape wastes 2 % fewer lanes at the frame's edges
+    int best = Y::WIDE ? 5 : 3;
     double best_eff = -1.0;
-    for (int l : {5, 4, 6, 3}) {
+    const int order[2][4] = {{3, 4, 5, 6}, {5, 4, 6, 3}};
+    for (int l : order[Y::WIDE ? 1 : 0]) {
         const int lw = 1 << l, lh = 64 >> l;
         const double eff = ((double)uw / (((uw + lw - 1) / lw) * lw)) * ((double)G.rows / (((G.rows + lh - 1) / lh) * lh));
         if (eff > best_eff + 0.02) { best_eff = eff; best = l; }
@@ -733,7 +743,7 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.max_code = (1 << depth) - 1;
     tg.rev = rev;
     tg.three = three ? 1 : 0;
-    const int node = (mode == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) ? 16 : 12;
+    const int node = ((mode == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) || (mode != LUTR_INTERP_TRILINEAR && LUTR_R2_NODE16)) ? 16 : 12;
     const long long room = 163840 - (long long)(three ? 3 : 1) * tg.tab_entries * 8 - r2::kWgq;
     const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
     tg.whole = whole_bytes <= room && !getenv("LUTR_NO_WHOLE");
