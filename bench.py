@@ -420,9 +420,10 @@ def host_us_per_apply(eng, job, args, n=1000):
     return out
 
 
-def load_traffic(tag):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if one exists for this workload."""
-    p = ROOT / "profiles" / "traffic.json"
+def load_traffic(tag, name="traffic.json"):
+    """HBM bytes per launch (or, with issue.json, the VALU issue figures) from the committed rocprofv3 --pmc summary, if one exists
+    for this workload."""
+    p = ROOT / "profiles" / name
     if p.exists():
         try:
             return json.loads(p.read_text()).get(tag)
@@ -626,6 +627,11 @@ def main():
                 "read_GBps": round((bpp_in * px_rank + lattice_bytes) / kern / 1e9, 1),
             },
         }
+        issue = load_traffic(tag, "issue.json") if traffic else None
+        if issue:
+            # what actually bounds the kernel: VALU instruction issue, from the same committed counter passes
+            result["roofline"]["valu_issue"] = dict(issue, note="committed rocprofv3 --pmc summary of this workload, NOT measured in this "
+                                                    "run: SQ_INSTS_VALU x 2.5 cycles / (1024 SIMDs x wave lifetime)")
         if other:
             result["other_precision"] = other
         if collective:

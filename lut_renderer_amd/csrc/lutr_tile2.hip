@@ -88,6 +88,9 @@
                                   // claim, the next tile's loads -- goes first, so memory operations leave as early as they can
                                   // (strict 587-589 -> 593 Gpx/s, fast +0.1 %); 2: the body goes first (-1.7 %); 0: off
 #endif
+#ifndef LUTR_T2_TRIREC
+#define LUTR_T2_TRIREC 1          // 1: fast trilinear stages node + r-difference records (Node::rec)
+#endif
 #ifndef LUTR_T2_NODE16
 #define LUTR_T2_NODE16 0          // 1: strict 4-tap kernels stage float4 nodes (one ds_read_b128 per tap, 4 LDS cycles) instead of 12-byte ones (ds_read2_b32 + ds_read_b32, 6 cycles)
 #endif
@@ -136,6 +139,24 @@ DEV float hsub_lo(uint32_t a, uint32_t b) { float d; asm("v_fma_mix_f32 %0, %1, 
 DEV float hsub_hi(uint32_t a, uint32_t b) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
 DEV float hlerp_lo(float t, float f, uint32_t v0) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(t), "v"(f), "v"(v0)); return d; }
 DEV float hlerp_hi(float t, float f, uint32_t v0) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(t), "v"(f), "v"(v0)); return d; }
+// fp16 difference * fp32 fraction + fp16 node: D in the low (D_HI = 0) or high half of `dw`, v0 in the low or high half of `vw`
+template <int D_HI, int V_HI> DEV float reclerp(uint32_t dw, float f, uint32_t vw)
+{
+    float d;
+    if constexpr (!D_HI && !V_HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(dw), "v"(f), "v"(vw));
+    else if constexpr (!D_HI && V_HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(dw), "v"(f), "v"(vw));
+    else if constexpr (D_HI && !V_HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(dw), "v"(f), "v"(vw));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(dw), "v"(f), "v"(vw));
+    return d;
+}
+DEV uint32_t f2h_bits(float v) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)v); }     // v_cvt_f16_f32, round to nearest even
+// the record of a node `a` whose r + 1 neighbour is `b` (both {r | g << 16, b} of fp16): differences exact in fp32, then rounded to fp16
+struct u3 { uint32_t x, y, z; };
+DEV u3 make_rec(uint2 a, uint2 b)
+{
+    const uint32_t dr = f2h_bits(hsub_lo(b.x, a.x)), dg = f2h_bits(hsub_hi(b.x, a.x)), db = f2h_bits(hsub_lo(b.y, a.y));
+    return u3{a.x, (a.y & 0xffffu) | (dr << 16), dg | (db << 16)};
+}
 
 // {a.x + s, a.y + s} in one v_pk_add_f32: op_sel_hi makes the high half read the LOW dword of the second operand too (the
 // compiler scalarises a splat add).  The second operand is a register pair whose high half is never read.
@@ -206,7 +227,12 @@ template <int INTERP, int V> struct Node {
     static constexpr bool fast = V == V_FAST;
     // bytes per node in a window: fast = four fp16 {r,g,b,-} (one ds_read_b64 per tap); strict 4-tap modes pack fp32 {r,g,b}
     // (a third more nodes per wave than float4; a tap is ds_read2_b32 + ds_read_b32); strict trilinear reads float4 nodes
-    static constexpr int lds = fast ? 8 : ((INTERP == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
+    // fast trilinear stages RECORDS: the node plus the fp16 difference to its r + 1 neighbour, {r | g << 16, b | Dr << 16, Dg | Db << 16}
+    // -- FFmpeg's first four lerps (along r) then take ONE v_fma_mix_f32 each instead of two, and a pixel reads 4 records instead of
+    // 8 nodes.  (The strict kernels cannot afford it: fp32 records are 24 bytes, the tube would shrink to 4 cells and the windows to
+    // nothing.)  The gather body rounds its differences to fp16 as well, so both paths compute the same number.
+    static constexpr bool rec = LUTR_T2_TRIREC && fast && INTERP == LUTR_INTERP_TRILINEAR;
+    static constexpr int lds = fast ? (rec ? 12 : 8) : ((INTERP == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
     static constexpr int glb = fast ? 8 : 16;                                              // bytes per node in HBM/L2
 };
 
@@ -812,6 +838,7 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
     for (int base = 0; base < total; base += 64 * kB) {
         int dst[kB];
         typename std::conditional<N::fast, uint2, float4>::type val[kB];
+        uint2 val1[N::rec ? kB : 1];                                          // records: the r + 1 neighbour
 #pragma unroll
         for (int k = 0; k < kB; k++) {
             const int i = min(base + k * 64 + lane, total - 1);              // the last batch re-reads the final node: harmless
@@ -824,11 +851,13 @@ DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG,
             dst[k] = slice_off + kLN * (__mul24(ir, sr) + __mul24(ig, nb) + ib);
             if constexpr (N::fast) val[k] = L.lat16[src];
             else val[k] = L.lat[src];
+            if constexpr (N::rec) val1[k] = L.lat16[__mul24(__mul24(min(r + 1, nmax), n1) + g, n1) + b];
         }
 #pragma unroll
         for (int k = 0; k < kB; k++) {
             char *q = smem + dst[k];
-            if constexpr (N::fast) *(uint2 *)q = val[k];
+            if constexpr (N::rec) { const u3 rc = make_rec(val[k], val1[k]); ((uint32_t *)q)[0] = rc.x; ((uint32_t *)q)[1] = rc.y; ((uint32_t *)q)[2] = rc.z; }
+            else if constexpr (N::fast) *(uint2 *)q = val[k];
             else if constexpr (kLN == 16) *(float4 *)q = val[k];
             else { ((float *)q)[0] = val[k].x; ((float *)q)[1] = val[k].y; ((float *)q)[2] = val[k].z; }
         }
@@ -921,19 +950,30 @@ DEV u2 tap16(const LutConsts &L, int a)
 DEV float tlerp(float v0, float v1, float f) { return v0 + (v1 - v0) * f; }
 
 // The taps of one pixel, loaded in one go so that several pixels' reads are in flight together (tile_body phases).
-template <int INTERP, int V> struct Taps {
-    static constexpr int n = INTERP == LUTR_INTERP_TRILINEAR ? 8 : (INTERP == LUTR_INTERP_NEAREST ? 1 : 4);
-    typename std::conditional<V == V_FAST, u2, f4>::type t[n];
+template <bool LDS, int INTERP, int V> struct Taps {
+    static constexpr bool rec = LDS && Node<INTERP, V>::rec;          // four records instead of eight nodes
+    static constexpr int n = rec ? 4 : (INTERP == LUTR_INTERP_TRILINEAR ? 8 : (INTERP == LUTR_INTERP_NEAREST ? 1 : 4));
+    typename std::conditional<rec, u3, typename std::conditional<V == V_FAST, u2, f4>::type>::type t[n];
 };
+DEV u3 tap_rec(int a)
+{
+    const __attribute__((address_space(3))) uint32_t *p = (const __attribute__((address_space(3))) uint32_t *)(uintptr_t)(unsigned)a;
+    return u3{p[0], p[1], p[2]};
+}
 
 template <bool LDS, int INTERP, int V>
-DEV Taps<INTERP, V> px_taps(const LutConsts &L, const Win &W, const PxC &c)
+DEV Taps<LDS, INTERP, V> px_taps(const LutConsts &L, const Win &W, const PxC &c)
 {
     using N = Node<INTERP, V>;
     constexpr int nb_ = LDS ? N::lds : N::glb;
     const int o_r = LDS ? W.o_r : nb_ * L.n1 * L.n1, o_g = LDS ? W.o_g : nb_ * L.n1;
     const int a = c.a;
-    Taps<INTERP, V> T;
+    Taps<LDS, INTERP, V> T;
+    if constexpr (Taps<LDS, INTERP, V>::rec) {
+        const int ag = a + o_g;
+        T.t[0] = tap_rec(a); T.t[1] = tap_rec(a + nb_); T.t[2] = tap_rec(ag); T.t[3] = tap_rec(ag + nb_);      // c00x c01x ... : (g, b) corners
+        return T;
+    } else {
     auto ld = [&](int addr) {
         if constexpr (N::fast) return tap16<LDS>(L, addr);
         else return tap<LDS, nb_>(L, addr);
@@ -948,13 +988,37 @@ DEV Taps<INTERP, V> px_taps(const LutConsts &L, const Win &W, const PxC &c)
         T.t[0] = ld(a); T.t[1] = ld(a + c.oa); T.t[2] = ld(a + c.oz); T.t[3] = ld(a + o_r + o_g + nb_);
     }
     return T;
+    }
 }
 
 // lattice value as the integer code it quantises to, held as float
-template <int INTERP, int V>
-DEV Rgb3 px_blend(const LutConsts &L, const PxC &c, const Taps<INTERP, V> &T)
+template <bool LDS, int INTERP, int V>
+DEV Rgb3 px_blend(const LutConsts &L, const PxC &c, const Taps<LDS, INTERP, V> &T)
 {
     Rgb3 v;
+    if constexpr (Taps<LDS, INTERP, V>::rec) {
+        // records {r | g << 16, b | Dr << 16, Dg | Db << 16} of the (g, b) corners 00, 01 (b + 1), 10 (g + 1), 11
+        const float dr = c.w01.x, dg = c.w01.y, db = c.w23.x;
+        {
+            const float c00 = reclerp<1, 0>(T.t[0].y, dr, T.t[0].x), c01 = reclerp<1, 0>(T.t[1].y, dr, T.t[1].x);
+            const float c10 = reclerp<1, 0>(T.t[2].y, dr, T.t[2].x), c11 = reclerp<1, 0>(T.t[3].y, dr, T.t[3].x);
+            const float c0 = fma_(c10 - c00, dg, c00), c1 = fma_(c11 - c01, dg, c01);
+            v.r = fma_(c1 - c0, db, c0);
+        }
+        {
+            const float c00 = reclerp<0, 1>(T.t[0].z, dr, T.t[0].x), c01 = reclerp<0, 1>(T.t[1].z, dr, T.t[1].x);
+            const float c10 = reclerp<0, 1>(T.t[2].z, dr, T.t[2].x), c11 = reclerp<0, 1>(T.t[3].z, dr, T.t[3].x);
+            const float c0 = fma_(c10 - c00, dg, c00), c1 = fma_(c11 - c01, dg, c01);
+            v.g = fma_(c1 - c0, db, c0);
+        }
+        {
+            const float c00 = reclerp<1, 0>(T.t[0].z, dr, T.t[0].y), c01 = reclerp<1, 0>(T.t[1].z, dr, T.t[1].y);
+            const float c10 = reclerp<1, 0>(T.t[2].z, dr, T.t[2].y), c11 = reclerp<1, 0>(T.t[3].z, dr, T.t[3].y);
+            const float c0 = fma_(c10 - c00, dg, c00), c1 = fma_(c11 - c01, dg, c01);
+            v.b = fma_(c1 - c0, db, c0);
+        }
+        return v;
+    } else
     if constexpr (V == V_FAST) {
         // nodes are fp16 of (lattice * M): the blend IS the code before truncation.  v_fma_mix_f32 takes the fp16 tap as it
         // is (exact conversion inside the instruction), fp32 weight, fp32 accumulator: one rounding per step.
@@ -962,8 +1026,14 @@ DEV Rgb3 px_blend(const LutConsts &L, const PxC &c, const Taps<INTERP, V> &T)
             v.r = mix0_lo(1.0f, T.t[0].x); v.g = mix0_hi(1.0f, T.t[0].x); v.b = mix0_lo(1.0f, T.t[0].y);
         } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
             const float dr = c.w01.x, dg = c.w01.y, db = c.w23.x;
-#define TRI16(SUB, LERP, W_, out) \
+            // (with records in LDS this is the gather body: its differences are rounded to fp16 as the staged ones are)
+#define TRI16(SUB_, LERP_, W_, out) \
             { \
+                auto SUB = [](uint32_t a_, uint32_t b_) { \
+                    const float d_ = SUB_(a_, b_); \
+                    if constexpr (Node<INTERP, V>::rec) return (float)(_Float16)d_; else return d_; \
+                }; \
+                auto LERP = [](float t_, float f_, uint32_t v0_) { return LERP_(t_, f_, v0_); }; \
                 const float c00 = LERP(SUB(T.t[4].W_, T.t[0].W_), dr, T.t[0].W_), c10 = LERP(SUB(T.t[6].W_, T.t[2].W_), dr, T.t[2].W_); \
                 const float c01 = LERP(SUB(T.t[5].W_, T.t[1].W_), dr, T.t[1].W_), c11 = LERP(SUB(T.t[7].W_, T.t[3].W_), dr, T.t[3].W_); \
                 const float c0 = fma_(c10 - c00, dg, c00), c1 = fma_(c11 - c01, dg, c01); \
@@ -1177,7 +1247,7 @@ DEV void tile_body(const LutConsts &L, const YuvConsts &K_, const Win &W_, const
 #pragma unroll
         for (int qb = 0; qb < 4; qb += TB) {
             PxC pc[TB];
-            Taps<INTERP, V> tp[TB];
+            Taps<LDS, INTERP, V> tp[TB];
 #pragma unroll
             for (int t = 0; t < TB; t++) {
                 pc[t] = px_finish<LDS, INTERP, V>(L, W, q.r[qb + t], q.g[qb + t], q.b[qb + t]);
@@ -1187,7 +1257,7 @@ DEV void tile_body(const LutConsts &L, const YuvConsts &K_, const Win &W_, const
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-            for (int t = 0; t < TB; t++) o[qb + t] = px_quant<INTERP, V>(L, px_blend<INTERP, V>(L, pc[t], tp[t]));
+            for (int t = 0; t < TB; t++) o[qb + t] = px_quant<INTERP, V>(L, px_blend<LDS, INTERP, V>(L, pc[t], tp[t]));
         }
         float rs[NCG], gs[NCG], bs[NCG];
 #if LUTR_T2_PK
@@ -1450,7 +1520,11 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         char *dst = smem + TG.tab_entries * 8 + kScratch;
         const int nodes = L.n1 * L.n1 * L.n1;
         for (int i = threadIdx.x; i < nodes; i += 64 * LUTR_T2_WPB) {
-            if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[i];
+            if constexpr (N::rec) {
+                const int plane = L.n1 * L.n1;
+                const u3 rc = make_rec(L.lat16[i], L.lat16[i + plane < nodes ? i + plane : i]);
+                uint32_t *q = (uint32_t *)(dst + 12 * i); q[0] = rc.x; q[1] = rc.y; q[2] = rc.z;
+            } else if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[i];
             else {
                 const float4 v = L.lat[i];
                 if constexpr (N::lds == 16) ((float4 *)dst)[i] = v;
@@ -1467,7 +1541,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         // four nodes per thread in flight: the staging is a chain of L2 round trips, and a short launch pays it in full
         constexpr int kSB = 4;
         for (int base = threadIdx.x; base < tube_nodes; base += kSB * 64 * LUTR_T2_WPB) {
-            int src[kSB];
+            int src[kSB], src1[kSB];
 #pragma unroll
             for (int k = 0; k < kSB; k++) {
                 const int i = min(base + k * 64 * LUTR_T2_WPB, tube_nodes - 1);
@@ -1475,17 +1549,21 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
                 const int gq = ir + ig - TG.tube_h - 1;
                 const int g = min(max(gq, 0), nmax), b = min(max((LUTR_T2_TUBE_BG ? gq : ir) + ib - TG.tube_h - 1, 0), nmax);
                 src[k] = (ir * L.n1 + g) * L.n1 + b;
+                src1[k] = (min(ir + 1, nmax) * L.n1 + g) * L.n1 + b;
             }
             typename std::conditional<N::fast, uint2, float4>::type val[kSB];
+            uint2 val1[N::rec ? kSB : 1];
 #pragma unroll
             for (int k = 0; k < kSB; k++) {
                 if constexpr (N::fast) val[k] = L.lat16[src[k]];
                 else val[k] = L.lat[src[k]];
+                if constexpr (N::rec) val1[k] = L.lat16[src1[k]];
             }
 #pragma unroll
             for (int k = 0; k < kSB; k++) {
                 const int i = min(base + k * 64 * LUTR_T2_WPB, tube_nodes - 1);      // (the last batch re-writes the final node: harmless)
-                if constexpr (N::fast) ((uint2 *)dst)[i] = val[k];
+                if constexpr (N::rec) { const u3 rc = make_rec(val[k], val1[k]); uint32_t *q = (uint32_t *)(dst + 12 * i); q[0] = rc.x; q[1] = rc.y; q[2] = rc.z; }
+                else if constexpr (N::fast) ((uint2 *)dst)[i] = val[k];
                 else if constexpr (N::lds == 16) ((float4 *)dst)[i] = val[k];
                 else { float *q = (float *)(dst + 12 * i); q[0] = val[k].x; q[1] = val[k].y; q[2] = val[k].z; }
             }
@@ -1840,7 +1918,8 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     tg.ch = ch; tg.nrc = (tg.nry + ch - 1) / ch; tg.nchunks = G.nframes * tg.nrc * tg.nsx;
     tg.tab_entries = vv >= V_TAB ? table_entries(K, din) : 0;
     tg.max_raw = (1 << din) - 1;
-    const int node = vv == V_FAST ? 8 : ((mode == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
+    const int node = vv == V_FAST ? ((LUTR_T2_TRIREC && mode == LUTR_INTERP_TRILINEAR) ? 12 : 8)
+                                  : ((mode == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
     const int blocks_per_cu = waves_per_cu / LUTR_T2_WPB > 0 ? waves_per_cu / LUTR_T2_WPB : 1;
     const int lds_block = 163840 / blocks_per_cu - tg.tab_entries * 8 - t2::kScratch;
     // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS

@@ -1015,16 +1015,20 @@ static inline void lut_pixel_fast(const uint16_t *l16, int n, int mode, const lu
             const rgbvec c010 = node16(l16, n, p[0], x[1], p[2]), c011 = node16(l16, n, p[0], x[1], x[2]);
             const rgbvec c100 = node16(l16, n, x[0], p[1], p[2]), c101 = node16(l16, n, x[0], p[1], x[2]);
             const rgbvec c110 = node16(l16, n, x[0], x[1], p[2]), c111 = node16(l16, n, x[0], x[1], x[2]);
+            /* The kernels stage each node with the fp16 difference to its r + 1 neighbour (csrc/lutr_tile2.hip Node::rec): the four  */
+            /* lerps along r use that rounded difference (the subtraction itself is exact in fp32), the later ones are plain fp32.  */
 #define FL(a, b, f) fmaf((b) - (a), (f), (a))
+#define FLR(a, b, f) fmaf(h2f(f2h_rne((b) - (a))), (f), (a))
 #define TRI16(ch) \
             { \
-                const float c00 = FL(c000.ch, c100.ch, dr), c10 = FL(c010.ch, c110.ch, dr); \
-                const float c01 = FL(c001.ch, c101.ch, dr), c11 = FL(c011.ch, c111.ch, dr); \
+                const float c00 = FLR(c000.ch, c100.ch, dr), c10 = FLR(c010.ch, c110.ch, dr); \
+                const float c01 = FLR(c001.ch, c101.ch, dr), c11 = FLR(c011.ch, c111.ch, dr); \
                 const float c0 = FL(c00, c10, dg), c1 = FL(c01, c11, dg); \
                 v.ch = FL(c0, c1, db); \
             }
             TRI16(r) TRI16(g) TRI16(b)
 #undef TRI16
+#undef FLR
 #undef FL
         } else {
             /* the kernels' sorted form: (1-x) c000 + (x-y) cA + (y-z) cB + z c111, cA one step along the axis of the

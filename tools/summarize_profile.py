@@ -85,10 +85,32 @@ if d:
         if alg:
             t = summary["kernel_time_us"]["mean_timed"] * 1e-6
             summary["kernel_time_us"]["roofline_frac_from_profile"] = round(alg / t / 1e9 / summary["bench"]["roofline"]["peak"], 4)
+# VALU issue: the tile kernels are persistent (every wave lives as long as the launch), SQ_WAVE_CYCLES counts in units of four
+# shader cycles, and one SIMD issues one wave-instruction per 2.5 cycles at best.
+c = summary.get("counters_mean_per_dispatch") or {}
+if "bench" in summary and all(k in c for k in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES")) and c["SQ_WAVES"] > 0:
+    px = summary["bench"]["value"] * 1e6 * summary["bench"]["ms_per_step"] * 1e-3
+    cycles = 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]
+    simds = 1024
+    summary["valu_issue"] = {
+        "valu_insts_per_px": round(c["SQ_INSTS_VALU"] * 64 / px, 1),
+        "lds_insts_per_px": round(c.get("SQ_INSTS_LDS", 0) * 64 / px, 2),
+        "shader_cycles_per_launch": round(cycles),
+        "shader_clock_GHz": round(cycles / (summary["kernel_time_us"]["mean_all"] * 1e3), 2) if "kernel_time_us" in summary else None,
+        "cycles_per_valu_inst_at_best": 2.5,
+        "frac_of_issue_limit": round(c["SQ_INSTS_VALU"] * 2.5 / (simds * cycles), 3),
+        "note": "SQ_INSTS_VALU x 2.5 cycles / (1024 SIMDs x wave lifetime): how close the launch is to one VALU instruction per 2.5 "
+                "cycles and SIMD, the best the unit does with any instruction mix (tools/ubench/op_rates2.hip)"}
 (dst / f"{rnd}_{tag}_counters.json").write_text(json.dumps(summary, indent=1) + "\n")
 if "hbm_bytes_per_launch" in summary and len(sys.argv) > 3:
     tpath = dst / "traffic.json"
     t = json.loads(tpath.read_text()) if tpath.exists() else {}
     t[sys.argv[3]] = int(summary["hbm_bytes_per_launch"]["total_corrected"])
     tpath.write_text(json.dumps(t, indent=1) + "\n")
+    if "valu_issue" in summary:
+        ipath = dst / "issue.json"
+        t = json.loads(ipath.read_text()) if ipath.exists() else {}
+        t[sys.argv[3]] = {k: summary["valu_issue"][k] for k in ("valu_insts_per_px", "lds_insts_per_px", "shader_clock_GHz", "frac_of_issue_limit")}
+        t[sys.argv[3]]["source"] = f"profiles/{rnd}_{tag}_counters.json"
+        ipath.write_text(json.dumps(t, indent=1) + "\n")
 print(json.dumps(summary, indent=1)[:3000])
