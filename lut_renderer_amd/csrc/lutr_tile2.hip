@@ -743,10 +743,13 @@ DEV int win_plane_stride(int nodes, int nb)
 
 template <int WIN, int INTERP, int PRE, int V>
 DEV bool restage(Win &W, const LutConsts &L, const YuvConsts &K, const Geom &TG, const Ext &e_, const Bnd &bn_, int slice_off,
-                 int scratch_off, int lane)
+                 int scratch_off, int lane_)
 {
     using N = Node<INTERP, V>;
     constexpr int kLN = N::lds;
+    // the lane id, recomputed: kept live from the kernel's start it is the one register the strict trilinear instance spilled to scratch
+    (void)lane_;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     Ext e = e_;
     Bnd bn = bn_;
     // side-effect free reductions would be hoisted out of the (rare) miss branch into every tile
