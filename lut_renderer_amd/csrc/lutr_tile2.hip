@@ -1387,6 +1387,10 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
 {
     using T = Tile<WIN, WOUT, CSX, CSY>;
     using N = Node<INTERP, V>;
+    // mixed tiles: the strict kernels (see the vote below); not trilinear with the prologue, whose body has no register left for the
+    // lanes' verdict (it spilled three VGPRs to scratch inside the body)
+    // (likewise 8-bit 4:4:4 trilinear: eight spilled registers)
+    constexpr bool kMixed = LUTR_T2_MIXED && V != V_FAST && !(INTERP == LUTR_INTERP_TRILINEAR && (PRE || (!WIN && !CSX)));
     LutConsts L = L_;
     YuvConsts K = K_;
     // a wave-uniform constant used by several VALU ops per pixel is worth a VGPR (an SGPR operand halves the issue rate
@@ -1626,7 +1630,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
                 // wave, its memory requests (what a gather costs) shrink to those lanes.
                 // (strict kernels only: with a cheap restage -- win_plane_stride -- the fast kernels' H = 8 tube and 367-node windows do as
                 // well or better without it: three times the chroma 540 vs 518 Gpx/s, sigma-16 526 vs 539, profiles/r03_exp16_*.txt)
-                if constexpr (LUTR_T2_MIXED && V != V_FAST)
+                if constexpr (kMixed)
                     if (!use_tube) mixed = __popcll(__ballot(!lane_in)) <= TG.mix_max;
             }
         }
@@ -1720,7 +1724,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
             }
         }
         bool gather = !use_lds;                      // whole tiles (wave-uniform) ...
-        if constexpr (LUTR_T2_MIXED && V != V_FAST) gather = gather || (mixed && !lane_in);     // ... or the outliers of a mixed tile (divergent)
+        if constexpr (kMixed) gather = gather || (mixed && !lane_in);     // ... or the outliers of a mixed tile (divergent)
         if (gather) {
             tile_body<false, WIN, WOUT, CSX, CSY, INTERP, PRE, V>(L, KB, W, TG, in, out); TK(tk_gath)
         }
