@@ -185,6 +185,9 @@ struct lutr_ctx {
     int pre_size = 0;
     float pre_min[3] = {0, 0, 0}, pre_scale[3] = {0, 0, 0};
     float *pre_dev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int    pre_shared[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // per depth: the three tables agree and never fall (LutConsts::pre_shared)
+    float  pre_kappa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // ... and their largest step between neighbouring codes
+    std::vector<float> pre_host[9];                         // ... and the shared table itself, codes 0 .. 2^depth - 1 (LutConsts::pre_host)
     // lutr_lut_broadcast: copies other contexts are still reading out of THIS context's lattice (one event per receiver,
     // recorded on the receiver's stream behind its copy).  The lattice must not be overwritten or freed before they finish.
     std::vector<std::pair<int, hipEvent_t>> readers;      // (receiver's device, event)
@@ -468,15 +471,19 @@ int lutr_ctx_set_prelut(lutr_ctx *c, const float *prelut, int size, const float 
 // The lattice coordinate of every integer code at this LUT depth with the prelut in front: FFmpeg's
 // prelut_interp_1d_linear on code * (1 / M), then * scale * (n - 1), clipped to [0, n - 1] -- per pixel in FFmpeg, per code here,
 // float for float the same operations (this file is compiled without contraction).  256 entries for 8-bit containers, else 65536.
-static int prelut_table(lutr_ctx *c, int depth, const float **dev, int *entries)
+static int prelut_table(lutr_ctx *c, int depth, const float **dev, int *entries, int *shared, float *kappa, const float **host_tab)
 {
-    *dev = nullptr; *entries = 0;
+    *dev = nullptr; *entries = 0; *shared = 0; *kappa = 0.0f; *host_tab = nullptr;
     if (!c->pre_size) return LUTR_OK;
     const int slot = depth - 8;
     if (slot < 0 || slot > 8) { set_error("prelut: LUT depth %d outside 8..16", depth); return LUTR_EINVAL; }
     const int ne = depth <= 8 ? 256 : 65536;
     *entries = ne;
-    if (c->pre_dev[slot]) { *dev = c->pre_dev[slot]; return LUTR_OK; }
+    if (c->pre_dev[slot]) {
+        *dev = c->pre_dev[slot]; *shared = c->pre_shared[slot]; *kappa = c->pre_kappa[slot];
+        *host_tab = c->pre_shared[slot] ? c->pre_host[slot].data() : nullptr;
+        return LUTR_OK;
+    }
     const int maxi = (1 << depth) - 1, pmax = c->pre_size - 1;
     const float scale_f = 1.0f / (float)maxi, lut_max = (float)(c->n - 1);
     std::vector<float> host((size_t)3 * ne);
@@ -501,6 +508,21 @@ static int prelut_table(lutr_ctx *c, int depth, const float **dev, int *entries)
     HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     c->pre_dev[slot] = (float *)p;
     *dev = c->pre_dev[slot];
+    // one table for the three channels?  (what the fused YUV tile kernels can take: their coordinate table is indexed by code alone,
+    // and their validity bounds want a monotone map with a known largest slope)
+    bool same = true;
+    float step = 0.0f;
+    for (int code = 0; code <= maxi && same; code++) {
+        const float v = host[code];
+        same = host[(size_t)ne + code] == v && host[(size_t)2 * ne + code] == v;
+        if (code) { const float d = v - host[code - 1]; if (d < 0.0f) same = false; else if (d > step) step = d; }
+    }
+    c->pre_shared[slot] = same ? 1 : 0;
+    c->pre_kappa[slot] = same ? step : 0.0f;
+    c->pre_host[slot].clear();
+    if (same) c->pre_host[slot].assign(host.begin(), host.begin() + maxi + 1);
+    *shared = c->pre_shared[slot]; *kappa = c->pre_kappa[slot];
+    *host_tab = same ? c->pre_host[slot].data() : nullptr;
     return LUTR_OK;
 }
 
@@ -627,7 +649,7 @@ static const uint2 *fast_lattice(lutr_ctx *c, int depth)
 static int fill_lut(LutConsts *L, lutr_ctx *c, int depth)
 {
     const int maxi = (1 << depth) - 1;
-    const int rc = prelut_table(c, depth, &L->pre, &L->pre_stride);
+    const int rc = prelut_table(c, depth, &L->pre, &L->pre_stride, &L->pre_shared, &L->pre_kappa, &L->pre_host);
     if (rc) return rc;
     L->lat = c->lat;
     L->lat16 = nullptr;

@@ -35,7 +35,11 @@ struct LutConsts {
     float maxf;          // (float)(2^depth - 1)
     int   unit;          // 1 when every lattice node is known to lie in [0, 1] (lets the tile kernels drop the output clip)
     const float *pre;    // lut3d's prelut folded into a per-code table of lattice coordinates (3 x pre_stride floats: the coordinate of
-    int   pre_stride;    // integer code i of channel c is pre[c * pre_stride + i]), or nullptr.  Only the generic / vector kernels read it.
+    int   pre_stride;    // integer code i of channel c is pre[c * pre_stride + i]), or nullptr.  The generic / vector kernels and the RGB
+                         // tube kernels read it per channel; the fused YUV tile kernels take it when it is `pre_shared`:
+    int   pre_shared;    // 1: the three channels' tables are identical and non-decreasing over the codes 0 .. 2^depth - 1 (the usual
+    float pre_kappa;     // cineSpace shaper): one coordinate table serves R, G and B; pre_kappa = the largest step between two codes (cells)
+    const float *pre_host; // HOST copy of that shared table (2^depth entries; launcher only: the tube's bound is read off the curve itself)
 };
 
 // Constant block of the YUV contract; same fields, same order as the

@@ -315,7 +315,10 @@ static bool plane_ok(const uint8_t *p, long long stride, long long fstride, long
 static const char *try_tile2(hipStream_t st, const LutConsts &L, const YuvConsts &K, const PlaneSet &P, const FrameGeom &G,
                              int din, int dout, int lut_depth, int csx, int csy, int mode, bool fast, unsigned *stats, unsigned *queue)
 {
-    if (getenv("LUTR_NO_TILE2") || L.pre) return nullptr;            // (a prelut: generic / vector kernels only)
+    // a prelut: only one that is the same non-decreasing shaper on the three channels (LutConsts::pre_shared) and only up to 10 bit (the
+    // coordinate table); anything else stays on the generic / vector kernels
+    const char *nop = getenv("LUTR_NO_TILE2_PRELUT");
+    if (getenv("LUTR_NO_TILE2") || (L.pre && (!L.pre_shared || lut_depth > 10 || (nop && nop[0] != '0')))) return nullptr;
     const int win = din > 8, wout = dout > 8, pxt = win ? 8 : 16, bh = 1 << csy;
     if (!(mode == LUTR_INTERP_NEAREST || mode == LUTR_INTERP_TRILINEAR || mode == LUTR_INTERP_TETRAHEDRAL)) return nullptr;
     if (G.w % pxt || G.row0 % bh || G.rows % bh || (csx == 0 && csy == 1)) return nullptr;
@@ -350,7 +353,7 @@ const char *launch_yuv(hipStream_t st, int variant, const LutConsts &L, const Yu
     const int win = din > 8, wout = dout > 8;
     const int pxt = win ? 8 : 16;
     const int bh = 1 << csy;
-    if (L.pre && variant == VAR_VEC_LDS) variant = VAR_VEC_GLOBAL;     // a prelut: the tile kernels do not read one
+    if (L.pre && !(L.pre_shared && lut_depth <= 10) && variant == VAR_VEC_LDS) variant = VAR_VEC_GLOBAL;   // a prelut the tile kernels cannot take
     if (variant == VAR_VEC_LDS || (variant == VAR_AUTO && !small_job((long long)G.w * G.rows * G.nframes, kSmallYuvMpx))) {
         if (const char *name = try_tile2(st, L, K, P, G, din, dout, lut_depth, csx, csy, mode, fast, stats, queue)) return name;
         if (variant == VAR_VEC_LDS) return nullptr;          // asked for the tile kernels, and they cannot take this call

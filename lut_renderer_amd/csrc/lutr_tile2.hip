@@ -295,7 +295,12 @@ template <int INTERP>
 DEV void coord_table_fill(const LutConsts &L, int entries)
 {
     for (int q = threadIdx.x; q < entries; q += 64 * LUTR_T2_WPB) {
-        const Crd c = crd_compute<INTERP>(L, fminf((float)q, L.maxf), L.sc[0]);
+        Crd c;
+        if (L.pre) {                 // a shared prelut (LutConsts::pre_shared): the folded coordinate of the code, then prev / frac as ever
+            const float s = L.pre[min(q, (int)L.maxf)];
+            if constexpr (INTERP == LUTR_INTERP_NEAREST) { const float fl = floorf(s); c.p = (s - fl >= .5f) ? fl + 1.0f : fl; c.d = 0.0f; }
+            else { c.p = floorf(s); c.d = s - c.p; }
+        } else c = crd_compute<INTERP>(L, fminf((float)q, L.maxf), L.sc[0]);
         *(float2 *)(smem + q * 8) = make_float2(c.p, c.d);
     }
     __syncthreads();
@@ -497,14 +502,16 @@ DEV Cells map_box(const LutConsts &L, const YuvConsts &K, const Geom &TG, float 
     // the second difference axis is (b - g) [LUTR_T2_WIN_BG] or (b - r)
     float g_lo = pg0 - pr1, g_hi = pg1 - pr0;                                                   // interval arithmetic
     float b_lo = LUTR_T2_WIN_BG ? pb0 - pg1 : pb0 - pr1, b_hi = LUTR_T2_WIN_BG ? pb1 - pg0 : pb1 - pr0;
-    if (L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2]) {
+    if (L.pre || (L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2])) {
         // chroma-only difference terms at the corners that extremise them: gv - rv falls in cb and in cr;
         // bu - rv rises in cb and falls in cr; bu - gv rises in both (gv1 = gv at (cb0, cr0), gv0 = gv at (cb1, cr1))
         float dg0 = gv0 - rv1, dg1 = gv1 - rv0;
         float db0 = LUTR_T2_WIN_BG ? bu0 - gv1 : bu0 - rv1, db1 = LUTR_T2_WIN_BG ? bu1 - gv0 : bu1 - rv0;
-        const bool clips = vr0 < 0.0f || vg0 < 0.0f || vb0 < 0.0f || vr1 >= m + 1.0f || vg1 >= m + 1.0f || vb1 >= m + 1.0f;
+        // (a shared prelut is a monotone map whose slope lies between 0 and pre_kappa cells per code: a code difference d moves the
+        // cell by at most pre_kappa |d| and possibly not at all -- the same one-sided form as where the clip can bind)
+        const bool clips = L.pre || vr0 < 0.0f || vg0 < 0.0f || vb0 < 0.0f || vr1 >= m + 1.0f || vg1 >= m + 1.0f || vb1 >= m + 1.0f;
         if (clips) { dg0 = fminf(dg0, 0.0f); dg1 = fmaxf(dg1, 0.0f); db0 = fminf(db0, 0.0f); db1 = fmaxf(db1, 0.0f); }
-        const float kappa = L.sc[0] * L.scale_f;
+        const float kappa = L.pre ? L.pre_kappa : L.sc[0] * L.scale_f;
         const float eps = m * (1.0f / 2097152.0f) + 1e-3f;                    // float rounding of the sums, and then some
         const float slack = 1.0f + 2.0f * L.lut_max * (1.0f / 2097152.0f) + 2e-3f;
         g_lo = fmaxf(g_lo, floorf(kappa * (dg0 - 1.0f - eps) - slack) + 1.0f);
@@ -1859,13 +1866,36 @@ struct Knob {
 #define T2_KNOB(NAME) ([]() -> const Knob & { static const Knob k(NAME); return k; }())
 }  // namespace
 
+// The tube's chroma bound under a shared prelut (LutConsts::pre_shared).  FFmpeg resamples a cineSpace shaper WITHOUT normalising the
+// interpolation weight by the segment width (parse_cinespace: `mix = x - in_prelut[idx]`), so the curve lut3d applies is a staircase:
+// nearly flat inside a segment, a jump at every input point -- its largest step between two codes says nothing about the rise over
+// 100.  What the tube needs is D(d) = max over x of s(x + d) - s(x), the most the coordinate can rise over d codes: two channel codes at
+// most d apart then sit at most floor(D(d)) + 1 cells apart.  Returns the largest d with D(d) <= h - 0.002 (0 if none).
+static int prelut_tube_bound(const float *s, int maxi, int h)
+{
+    struct Memo { const float *s; int maxi, h, d; float first, last; };
+    static thread_local Memo memo = {nullptr, 0, 0, 0, 0.0f, 0.0f};
+    if (!s || maxi < 1) return 0;
+    if (memo.s == s && memo.maxi == maxi && memo.h == h && memo.first == s[1] && memo.last == s[maxi]) return memo.d;
+    const float lim = (float)h - 2e-3f;
+    int d = 0;
+    for (int cand = 1; cand <= maxi; cand++) {
+        float rise = 0.0f;
+        for (int x = 0; x + cand <= maxi; x++) rise = fmaxf(rise, s[x + cand] - s[x]);
+        if (rise > lim) break;
+        d = cand;
+    }
+    memo = Memo{s, maxi, h, d, s[1], s[maxi]};
+    return d;
+}
+
 // Which variant serves this call?
 static int tile2_variant(const LutConsts &L, const YuvConsts &K, int lut_depth, int csx, int csy, bool fast)
 {
-    const bool eq = L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2];
-    const bool tab = eq && lut_depth <= 10 && !T2_KNOB("LUTR_NO_TAB");
+    const bool eq = L.pre ? L.pre_shared != 0 : (L.sc[0] == L.sc[1] && L.sc[1] == L.sc[2]);      // one coordinate table for R, G and B
+    const bool tab = eq && lut_depth <= 10 && (L.pre || !T2_KNOB("LUTR_NO_TAB"));
     const bool unit = L.unit && out_clip_dead(K, 1 << (csx + csy));
-    if (fast && tab && unit && L.lat16) return t2::V_FAST;
+    if (fast && tab && unit && L.lat16 && !L.pre) return t2::V_FAST;      // (the fast variant is defined without a prelut: its CPU twin has none)
     if (tab && unit) return t2::V_UNIT;
     if (tab) return t2::V_TAB;
     return t2::V_GEN;
@@ -1881,6 +1911,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     const bool pre = K.pre != 0.0f;
     const int v = tile2_variant(L, K, lut_depth, csx, csy, fast);
     if (pre && v != V_UNIT && v != V_FAST) return nullptr;
+    if (L.pre && v < V_TAB) return nullptr;                   // a prelut lives in the coordinate table: the general variant computes
     // nearest has no blend to speed up and no prologue instances: strict clip-free kernel, or the round-1 path
     if (mode == LUTR_INTERP_NEAREST && pre) return nullptr;
     const int vv = (mode == LUTR_INTERP_NEAREST && v == V_FAST) ? V_UNIT : v;
@@ -1948,7 +1979,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         // (UHD, 8 / 16 / 32 / 64 frames per launch, Gpx/s at H = 8 | 5: 351 | 369, 445 | 456, 533 | 541, 598 | 595)
         if ((long long)G.nframes * tg.nsx * tg.nry < 100ll * max_waves) h = (5 * (L.n1 - 2) + 16) / 32;
         if (const Knob &e = T2_KNOB("LUTR_TUBE_H")) h = e.num();
-        const float kappa = L.sc[0] * L.scale_f;
+        const float kappa = L.pre ? fmaxf(L.pre_kappa, 1e-6f) : L.sc[0] * L.scale_f;   // cells per code, at most (a shared prelut: its largest step)
         const float eps = K.max_l * (1.0f / 2097152.0f) + 1e-3f;                 // as map_box
         const float slack = 1.0f + 2.0f * L.lut_max * (1.0f / 2097152.0f) + 2e-3f;
         // fast (8-byte nodes): at most 70 % of the block's LDS and windows of >= 256 nodes (H = 8 / 367 at 33^3).  The strict 4-tap
@@ -1960,8 +1991,10 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
         while (h >= 3) {
             const long long nb = 2 * h + 3, plane = T2_KNOB("LUTR_TUBE_NOPAD") ? nb * nb : tube_plane_stride((int)nb, node);
             const long long bytes = (long long)L.n1 * plane * node;
-            const float t = ((float)(h + 1) - slack) / kappa - 1.0f - eps;
-            if (bytes <= (long long)lds_block * tube_pct / 100 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= min_win && t > 0.0f) {
+            const bool fits = bytes <= (long long)lds_block * tube_pct / 100 && (lds_block - bytes) / (node * LUTR_T2_WPB) >= min_win;
+            float t = ((float)(h + 1) - slack) / kappa - 1.0f - eps;
+            if (L.pre) t = fits ? prelut_tube_bound(L.pre_host, (int)L.maxf, h) - 0.5f - eps : 0.0f;      // (a scan of the curve: memoised)
+            if (fits && t > 0.0f) {
                 tg.tube_h = h; tg.tube_t = t; tg.tube_plane = (int)plane; tube_bytes = bytes;
                 break;
             }

@@ -371,6 +371,92 @@ def test_prelut_and_per_channel_domains_on_the_tube_kernels(engine, orc, tmp_pat
         engine.set_variant("auto")
 
 
+def test_shared_prelut_on_the_fused_yuv_tile_kernels(engine, orc, tmp_path):
+    """VERDICT r2 missing #5, the YUV side: a cineSpace file whose three shapers are the same non-decreasing curve (the usual
+    case) runs on k_yuv_tile2 -- the coordinate table is filled from the folded prelut, the tube and the windows take their slope
+    bound from its largest step.  10 and 8 bit, three modes, content that stays in the tube, leaves it, and fills the windows and
+    the gather path, the full-range prologue, a ragged shard.  A shaper that falls, or differs per channel, stays off the tile
+    kernels; the fast precision has no prelut and runs the strict kernel."""
+    from tests.test_lut_formats import _csp_with_prelut
+    n = 33                      # (17^3 would fit LDS whole: no tube, no windows, nothing to prove)
+    tab = cube.log709_lattice(n)
+    xs = np.linspace(0.0, 1.0, 33)
+    curve = (xs, xs ** 0.55)
+    p = tmp_path / "shared.csp"
+    _csp_with_prelut(p, n, tab, [curve] * 3)
+    lut = cube.read_lut(p)
+    n2, s2, t2, pre = orc.parse_lut_file_ex(p)
+    engine.set_lut(lut)
+    try:
+        engine.set_variant("vec_lds")
+        for depth, fmt in ((10, "yuv420p10le"), (8, "yuv420p"), (10, "yuv444p10le")):
+            dt = np.uint16 if depth > 8 else np.uint8
+            cs = (0, 0) if "444" in fmt else (1, 1)
+            k = orc.yuv_constants(din=depth, dl=depth, dout=depth, chroma_n=1 << sum(cs))
+            for dist in ("natural", "vivid", "noise16", "uniform"):
+                src = frames.make_yuv(dist, 512, 136, depth, cs[0], cs[1], k=81)
+                for mode in MODES3:
+                    got = engine.apply_yuv(_to_dev(src, engine.device), pix_fmt=fmt, interp=mode)
+                    assert "k_yuv_tile2" in engine.last_kernel and "fast" not in engine.last_kernel, engine.last_kernel
+                    want = orc.apply_yuv(t2, s2, mode, k, depth, depth, depth, cs[0], cs[1], src, prelut=pre)
+                    _assert_equal(_to_np(got, dt), want, f"shared prelut {fmt} {mode} {dist}")
+        # That curve is 4.8 times steeper near black than on average, and the tube's bound has to assume the steepest slope everywhere:
+        # its tiles went through the windows.  A gentle shaper (slope within 1 +- 0.4) leaves the tube in business:
+        mild = (xs, xs + 0.4 * xs * (1.0 - xs))
+        pm = tmp_path / "mild.csp"
+        _csp_with_prelut(pm, n, tab, [mild] * 3)
+        engine.set_lut(cube.read_lut(pm))
+        _, sm, tm, prem = orc.parse_lut_file_ex(pm)
+        k = orc.yuv_constants(din=10)
+        for dist in ("natural", "noise16"):
+            src = frames.make_yuv(dist, 1024, 256, 10, 1, 1, k=82)
+            engine.tile_stats(True)
+            got = engine.apply_yuv(_to_dev(src, engine.device), pix_fmt="yuv420p10le")
+            st = engine.tile_stats(False)
+            # (tube body for the whole tile, or for all but a few outlier lanes)
+            assert st["tiles"] > 0 and st["tube_tiles"] + st["mixed_tiles"] > st["tiles"] // 2 and "+tube" in engine.last_kernel, (st, engine.last_kernel)
+            _assert_equal(_to_np(got, np.uint16), orc.apply_yuv(tm, sm, "tetrahedral", k, 10, 10, 10, 1, 1, src, prelut=prem), f"mild shaper {dist}")
+        engine.set_lut(lut)
+        # the config-5 prologue in front, 10 -> 8 bit LUT depth
+        k5 = orc.yuv_constants("bt709", "tv", "bt709", "tv", 10, 8, 10, 4, prologue=True)
+        src = frames.make_yuv("natural", 256, 72, 10, 1, 1, k=83, full_range=True)
+        got = engine.apply_yuv(_to_dev(src, engine.device), pix_fmt="yuv420p10le", range_src="pc", range_in="tv", lut_depth=8)
+        assert "tile2" in engine.last_kernel and "pre" in engine.last_kernel, engine.last_kernel
+        _assert_equal(_to_np(got, np.uint16), orc.apply_yuv(t2, s2, "tetrahedral", k5, 10, 8, 10, 1, 1, src, prelut=pre), "shared prelut + prologue")
+        # rows 8..71 of a taller frame (a row shard)
+        k = orc.yuv_constants(din=10)
+        src = frames.make_yuv("vivid", 256, 96, 10, 1, 1, k=84)
+        dev = _to_dev(src, engine.device)
+        out = [t.clone() for t in dev]
+        engine.apply_yuv(dev, out, pix_fmt="yuv420p10le", row0=8, rows=64)
+        want = orc.apply_yuv(t2, s2, "tetrahedral", k, 10, 10, 10, 1, 1, src, prelut=pre)
+        ref = [a.copy() for a in src]
+        ref[0][8:72] = want[0][8:72]; ref[1][4:36] = want[1][4:36]; ref[2][4:36] = want[2][4:36]
+        _assert_equal(_to_np(out, np.uint16), ref, "shared prelut shard")
+        # fast precision: no prelut there -> the strict tile kernel
+        engine.set_precision("fast")
+        src = frames.make_yuv("natural", 256, 72, 10, 1, 1, k=85)
+        got = engine.apply_yuv(_to_dev(src, engine.device), pix_fmt="yuv420p10le")
+        assert "tile2" in engine.last_kernel and "fast" not in engine.last_kernel, engine.last_kernel
+        _assert_equal(_to_np(got, np.uint16), orc.apply_yuv(t2, s2, "tetrahedral", k, 10, 10, 10, 1, 1, src, prelut=pre), "shared prelut, fast asked")
+        engine.set_precision("strict")
+        # a shaper that falls somewhere (lut3d accepts it) and one that differs per channel: not for the tile kernels
+        bump = (np.array([0.0, 0.3, 0.5, 0.7, 1.0]), np.array([0.0, 0.45, 0.4, 0.8, 1.0]))
+        for name, shapers in (("falls.csp", [bump] * 3), ("differs.csp", [curve, curve, (xs, xs ** 0.6)])):
+            q = tmp_path / name
+            _csp_with_prelut(q, n, tab, shapers)
+            lut2 = cube.read_lut(q)
+            _, s3, t3, pre3 = orc.parse_lut_file_ex(q)
+            engine.set_lut(lut2)
+            src = frames.make_yuv("natural", 256, 72, 10, 1, 1, k=86)
+            got = engine.apply_yuv(_to_dev(src, engine.device), pix_fmt="yuv420p10le")
+            assert "tile" not in engine.last_kernel, (name, engine.last_kernel)
+            _assert_equal(_to_np(got, np.uint16), orc.apply_yuv(t3, s3, "tetrahedral", k, 10, 10, 10, 1, 1, src, prelut=pre3), name)
+    finally:
+        engine.set_precision("strict")
+        engine.set_variant("auto")
+
+
 def test_soak_rgb_tube_kernels_against_the_generic_kernel():
     """tools/soak_rgb.py for a few seconds: random lattices, domains, formats, orders, modes, shards and content swept across the
     tube's limit in every direction, the tube kernels against the scalar kernel sample by sample (a long run is in DESIGN.md 7)."""

@@ -46,13 +46,23 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     eng = LutEngine(0)
     rng = np.random.default_rng(20261004)
-    t0, runs, px, tube_tiles, tiles, fast_runs = time.time(), 0, 0, 0, 0, 0
+    t0, runs, px, tube_tiles, tiles, fast_runs, pre_runs = time.time(), 0, 0, 0, 0, 0, 0
     fmts = [("yuv420p10le", 10, 1, 1), ("yuv420p", 8, 1, 1), ("yuv422p10le", 10, 1, 0), ("yuv444p10le", 10, 0, 0), ("yuv444p", 8, 0, 0)]
     while time.time() - t0 < budget:
         n = int(rng.choice([22, 26, 29, 33, 33, 33, 37, 40, 41, 65]))
         lat = rng.uniform(0.0, 1.0, size=(n, n, n, 3)).astype(np.float32) if rng.random() < 0.3 else cube.log709_lattice(n)
         scale = np.array([1.0, 1.0, 1.0], np.float32) if rng.random() < 0.7 else np.full(3, rng.uniform(0.6, 1.0), np.float32)
-        eng.set_lut(cube.CubeLut(n, scale, lat))
+        pre = None
+        if rng.random() < 0.3:
+            # a shaper shared by the three channels (what the fused tile kernels take since round 3): random non-decreasing curve with
+            # flat and steep stretches, so the slope bound the tube and the windows rest on (LutConsts::pre_kappa) is far from the mean slope
+            size = int(rng.choice([17, 64, 256, 1024]))
+            steps = rng.gamma(0.4, 1.0, size=size - 1) * (rng.random(size - 1) < 0.8)
+            curve = np.concatenate([[0.0], np.cumsum(steps)])
+            curve = (curve / max(curve[-1], 1e-9) * rng.uniform(0.7, 1.0)).astype(np.float32)
+            pre = cube.Prelut(np.stack([curve] * 3), np.zeros(3, np.float32), np.full(3, size - 1, np.float32))
+            pre_runs += 1
+        eng.set_lut(cube.CubeLut(n, scale, lat, prelut=pre))
         fmt, depth, csx, csy = fmts[rng.integers(0, len(fmts))]
         w, h = int(rng.choice([512, 1024, 1920])), int(rng.choice([64, 136, 270]) * 2)
         ragged = rng.random() < 0.25          # a width the 16-byte kernels cannot take whole: "auto" splits it, tile kernels + scalar rest
@@ -72,6 +82,8 @@ def main():
         a = [t.clone() for t in eng.apply_yuv(dev, **kw)]
         st = eng.tile_stats(False)
         name = eng.last_kernel
+        if pre is not None and not ragged and "tile2" not in name:        # (a ragged width on unpadded rows is the scalar kernel's)
+            raise SystemExit(f"run {runs}: a shared prelut did not take the tile kernels: {name} {fmt} {kw}")
         eng.set_variant("generic")
         b = eng.apply_yuv(dev, **kw)
         r0, rn = kw.get("row0", 0), kw.get("rows", h)
@@ -99,7 +111,7 @@ def main():
         px += 4 * w * h
         tube_tiles += st["tube_tiles"]
         tiles += st["tiles"]
-    print(f"soak ok: {runs} runs ({fast_runs} also with the fast kernels), {px / 1e6:.0f} Mpx compared, {tiles} tiles "
+    print(f"soak ok: {runs} runs ({fast_runs} also with the fast kernels, {pre_runs} with a shared prelut), {px / 1e6:.0f} Mpx compared, {tiles} tiles "
           f"({tube_tiles} through the tube), {time.time() - t0:.0f} s")
 
 
