@@ -166,7 +166,7 @@ struct lutr_ctx {
     int variant = VAR_AUTO;
     std::string last_kernel;
     bool unit = false;               // every lattice node known to lie in [0, 1]
-    unsigned *queue = nullptr;       // work-queue counter of the tile kernels (device), zeroed per launch
+    unsigned *queue = nullptr;       // work-queue words of the tile kernels (device, 4 words: see lutr_ctx_create)
     float *fscratch = nullptr;       // float planes of the dither path
     size_t fscratch_floats = 0;
     unsigned *stats = nullptr;       // 8 device counters (4 reported + clock stamps), see lutr_ctx_tile_stats
@@ -269,8 +269,12 @@ int lutr_ctx_create(int device, lutr_ctx **out)
         return hip_fail(e, "hipStreamCreateWithFlags");
     }
     c->stream = c->own_stream;
-    e = hipMalloc((void **)&c->queue, sizeof(unsigned));
+    // four words: {claims, waves done} of the round-3 tile kernels, which return them to zero themselves at the end of every launch
+    // (no memset node per launch), word 2 for round 1's RGB kernel (set by its launcher), one spare
+    e = hipMalloc((void **)&c->queue, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(c->queue, 0, 4 * sizeof(unsigned));
     if (e != hipSuccess) {
+        if (c->queue) (void)hipFree(c->queue);
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         return hip_fail(e, "hipMalloc(queue)");

@@ -89,7 +89,8 @@ struct Geom {
     int tube_h, tube_plane;
     int rev;              // memory order of the components is B, G, R: strides permuted, nodes staged with R and B swapped
     int three;            // three coordinate tables (one per channel: a prelut, or DOMAIN scales that differ), else one
-    unsigned *queue, *stats;
+    unsigned *queue, *stats;      // queue: device words {claims, waves done}, both 0 between launches (queue_leave, as lutr_tile2.hip)
+    unsigned qbase;               // waves in the grid = the first chunk the counter hands out
 };
 
 struct Planes {
@@ -460,7 +461,7 @@ DEV bool claim_chunk(const Geom &TG, int lane, int wgq_off, int &fr, int &sx, in
     const unsigned j = t >> 4, slot = t & 15u, r = j & 7u;
     if (slot == 0) {
         if (lane == 0) {
-            c = atomicAdd(TG.queue, 16u);
+            c = atomicAdd(TG.queue, 16u) + TG.qbase;
             q[8 + r] = c;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             q[16 + r] = j + 1u;
@@ -471,6 +472,24 @@ DEV bool claim_chunk(const Geom &TG, int lane, int wgq_off, int &fr, int &sx, in
         c = (unsigned)uni((int)q[8 + r]) + slot;
     }
     return chunk_at(TG, c, fr, sx, ry, rem);
+}
+
+// a wave that will claim no more; the last one zeroes the two words for the next launch (no memset node per launch)
+DEV void queue_leave(const Geom &TG, int lane, int wgq_off)
+{
+    // two levels, like the claims: the waves of a workgroup count themselves out in LDS (word 24 of the allocator's block), the last one
+    // reports the workgroup -- 4096 atomics on one address at the end of a short launch cost it 15 us
+    if (lane == 0) {
+        const lds_vup q = (lds_vup)(uintptr_t)(unsigned)(lds_base() + wgq_off);
+        const unsigned left = __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned *)(q + 24), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (left == (unsigned)LUTR_R2_WPB - 1u) {
+            const unsigned done = atomicAdd(TG.queue + 1, 1u);
+            if (done == gridDim.x - 1u) {
+                __hip_atomic_store(TG.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(TG.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 template <int LY, int INTERP, int TAB, bool UNIT>
@@ -534,7 +553,7 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
     }
     int fr, sx, ry, rem;
     bool first = true;
-    if (!claim_chunk(TG, lane, wgq_off, fr, sx, ry, rem, first)) return;
+    if (!claim_chunk(TG, lane, wgq_off, fr, sx, ry, rem, first)) { queue_leave(TG, lane, wgq_off); return; }
     const int lw = 1 << TG.lw_log2, lh_log2 = 6 - TG.lw_log2;
     const int lx = lane & (lw - 1), ly = lane >> TG.lw_log2;
     constexpr int UB = Y::NW * 4;                       // bytes of a unit per plane
@@ -629,6 +648,7 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
             for (int p = 0; p < Y::NPL; p++) stw<Y::NW>(cp.d[p] + (__umul24(lyc, P.ds[p]) + lxc * UB), out.w[p]);
         }
     }
+    queue_leave(TG, lane, wgq_off);
     if (TG.stats && lane == 0) {
         atomicAdd(&TG.stats[0], st_tiles); atomicAdd(&TG.stats[2], st_gather); atomicAdd(&TG.stats[12], st_tube);
     }
@@ -773,7 +793,7 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     if (getenv("LUTR_DEBUG"))
         fprintf(stderr, "[lutr r2] layout %d nsx %d nry %d chunk %d chunks %d blocks %u lds %zu tab %d whole %d tube h %d plane %d rev %d\n",
                 LY, tg.nsx, tg.nry, tg.ch, tg.nchunks, grid.x, lds, tg.tab_entries, tg.whole, tg.tube_h, tg.tube_plane, rev);
-    if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_R2_WPB), 1, st) != hipSuccess) return nullptr;
+    tg.qbase = grid.x * LUTR_R2_WPB;      // (the counter is at zero: the previous launch left it so)
     const bool unit = L.unit != 0;
 
 #define R2_LAUNCH(I, T, U, NAME) \

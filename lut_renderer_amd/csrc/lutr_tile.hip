@@ -867,6 +867,9 @@ const char *launch_rgb_tile(hipStream_t st, const LutConsts &L, const PlaneSet &
     plan_tiles(&tg, G.w / pxt, G.rows, G.nframes, g_win_nodes, g_waves_per_cu, stats, queue);
     const dim3 grid(tile_blocks(tg, g_waves_per_cu)), block(64 * LUTR_WPB);
     // the queue starts behind the chunks the waves take by their id (claim_chunk)
+    // (round 1's single counter keeps its memset, on a word of its own: words 0 and 1 of the block belong to the round-3 kernels, which
+    // leave them at zero themselves)
+    queue += 2; tg.queue = queue;
     if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_WPB * LUTR_STATIC_ROUNDS), 1, st) != hipSuccess) return nullptr;
     const bool tab = plan_table(&tg, L, lds_node_rt(mode)) != 0;
     const TilePlanes TP = tile_planes(P);

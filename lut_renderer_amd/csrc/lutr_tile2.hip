@@ -211,7 +211,9 @@ struct Geom {
     float tube_t;         // the test: |gv - rv| and |bu - rv| (RGB codes, chroma only) must stay <= tube_t over the lane's unit
     unsigned tube_rlo, tube_rhi;   // a raw chroma interval [lo, hi] (packed like the window boxes) that implies the test for both planes:
                                    // four saturating subtractions instead of ~35 VALU for the tiles that fit it (tube_rlo > tube_rhi: none)
-    unsigned *queue;      // device counter, set by the launcher before every launch
+    unsigned *queue;      // device words {claims, waves done}: both 0 between launches -- the last wave to leave resets them (queue_leave),
+                          // so a launch needs no memset node in front of it
+    unsigned qbase;       // waves in the grid = the first chunk the counter hands out (the waves' ids come before it)
     unsigned *stats;      // optional device counters; nullptr = off
 };
 
@@ -1371,7 +1373,7 @@ DEV bool claim_chunk(const Geom &TG, int lane, int wgq_off, int &fr, int &sx, in
     const unsigned j = t >> 4, slot = t & 15u, r = j & 7u;
     if (slot == 0) {
         if (lane == 0) {
-            c = atomicAdd(TG.queue, 16u);
+            c = atomicAdd(TG.queue, 16u) + TG.qbase;
             q[8 + r] = c;                                  // base[r]
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             q[16 + r] = j + 1u;                            // ready[r]
@@ -1382,10 +1384,29 @@ DEV bool claim_chunk(const Geom &TG, int lane, int wgq_off, int &fr, int &sx, in
         c = (unsigned)uni((int)q[8 + r]) + slot;
     }
 #else
-    if (lane == 0) c = atomicAdd(TG.queue, 1u);
+    if (lane == 0) c = atomicAdd(TG.queue, 1u) + TG.qbase;
     c = (unsigned)uni((int)c);
 #endif
     return chunk_at(TG, c, fr, sx, ry, rem);
+}
+
+// Every wave calls this once, when it will claim no more: the last one puts the two words back to zero for the next launch.  (A wave's
+// claims have returned before it gets here -- it needed their values -- so the plain stores cannot overtake anybody's atomic.)
+DEV void queue_leave(const Geom &TG, int lane, int wgq_off)
+{
+    // two levels, like the claims: the waves of a workgroup count themselves out in LDS (word 24 of the allocator's block), the last one
+    // reports the workgroup -- 4096 atomics on one address at the end of a short launch cost it 15 us
+    if (lane == 0) {
+        const lds_vup q = (lds_vup)(uintptr_t)(unsigned)(lds_base() + wgq_off);
+        const unsigned left = __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned *)(q + 24), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (left == (unsigned)LUTR_T2_WPB - 1u) {
+            const unsigned done = atomicAdd(TG.queue + 1, 1u);
+            if (done == gridDim.x - 1u) {
+                __hip_atomic_store(TG.queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(TG.queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 template <int WIN, int WOUT, int CSX, int CSY, int INTERP, int PRE, int V>
@@ -1585,7 +1606,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         __syncthreads();
     }
     __syncthreads();                          // (the allocator's LDS words are initialised; the general variant has no other barrier)
-    if (!have_work) return;                   // (after the barriers above: every wave of the workgroup takes part in the staging)
+    if (!have_work) { queue_leave(TG, lane, wgq_off); return; }      // (after the barriers above: every wave of the workgroup takes part in the staging)
 
     for (bool more = true; more;) {
         TileIn<WIN, WOUT, CSX, CSY> in = nxt;
@@ -1761,6 +1782,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
         atomicAdd(&TG.stats[11], tk_wait >> 4); atomicAdd(&TG.stats[8], tk_body >> 4); atomicAdd(&TG.stats[9], tk_gath >> 4); atomicAdd(&TG.stats[10], tk_store >> 4);
     }
 #endif
+    queue_leave(TG, lane, wgq_off);
     if (TG.stats && lane == 0) {
         atomicAdd(&TG.stats[0], st_tiles); atomicAdd(&TG.stats[1], cnt[1]);
         atomicAdd(&TG.stats[2], cnt[8]); atomicAdd(&TG.stats[3], cnt[9]); atomicAdd(&TG.stats[6], cnt[0]);
@@ -2041,7 +2063,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     tg.queue = queue; tg.stats = stats;
     const int waves = tg.nchunks < max_waves ? tg.nchunks : max_waves;
     const dim3 grid((waves + LUTR_T2_WPB - 1) / LUTR_T2_WPB), block(64 * LUTR_T2_WPB);
-    if (hipMemsetD32Async((hipDeviceptr_t)queue, (int)(grid.x * LUTR_T2_WPB), 1, st) != hipSuccess) return nullptr;
+    tg.qbase = grid.x * LUTR_T2_WPB;      // (the counter is at zero: the previous launch left it so)
     const size_t lds = (size_t)tg.tab_entries * 8 + kScratch +
                        (tg.whole ? (size_t)whole_bytes : (size_t)tube_bytes + (size_t)LUTR_T2_WPB * tg.win_nodes * node);
     Planes2 TP;
