@@ -88,6 +88,10 @@
                                   // claim, the next tile's loads -- goes first, so memory operations leave as early as they can
                                   // (strict 587-589 -> 593 Gpx/s, fast +0.1 %); 2: the body goes first (-1.7 %); 0: off
 #endif
+#ifndef LUTR_T2_MIXED_FAST
+#define LUTR_T2_MIXED_FAST 0      // 1: mixed tiles for the fast kernels too: sigma-16 frames 512 -> 537 Gpx/s, natural 662 -> 655, saturated 530 -> 522
+                                  // (10 more VGPRs in a kernel that has them to lose; profiles/r03_exp34_mixed_tiles_fast_kernels.txt): off
+#endif
 #ifndef LUTR_T2_TRIREC
 #define LUTR_T2_TRIREC 1          // 1: fast trilinear stages node + r-difference records (Node::rec)
 #endif
@@ -1418,7 +1422,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     // mixed tiles: the strict kernels (see the vote below); not trilinear with the prologue, whose body has no register left for the
     // lanes' verdict (it spilled three VGPRs to scratch inside the body)
     // (likewise 8-bit 4:4:4 trilinear: eight spilled registers)
-    constexpr bool kMixed = LUTR_T2_MIXED && V != V_FAST && !(INTERP == LUTR_INTERP_TRILINEAR && (PRE || (!WIN && !CSX)));
+    constexpr bool kMixed = LUTR_T2_MIXED && (V != V_FAST || LUTR_T2_MIXED_FAST) && !(INTERP == LUTR_INTERP_TRILINEAR && (PRE || (!WIN && !CSX)));
     LutConsts L = L_;
     YuvConsts K = K_;
     // a wave-uniform constant used by several VALU ops per pixel is worth a VGPR (an SGPR operand halves the issue rate
