@@ -204,7 +204,8 @@ struct Geom {
     int win_nodes;        // LDS window capacity per wave, in nodes
     int tab_entries;      // per-code coordinate table at LDS offset 0 (0 = coordinates are computed)
     int max_raw;          // 2^din - 1: a raw code above it cannot be trusted to stay inside the table
-    int whole;            // 1: the WHOLE lattice fits the workgroup's LDS (N <= 21 strict / 25 fast at 10 bit): staged once
+    int whole;            // 1: the WHOLE lattice fits the workgroup's LDS (N <= 21 strict / 25 fast at 10 bit): staged once,
+    int whole_a, whole_b; //    node (r, g, b) at index r * whole_a + g * whole_b + b (strides padded against LDS bank conflicts)
                           // per workgroup, shared by its waves, no windows, no validity tests -- content cannot matter
     int tube_h;           // > 0: a workgroup-shared "grey tube" of the lattice is staged once, behind the scratch area: every cell with
                           // |pg - pr| <= tube_h and |pb - pr| <= tube_h, all of r.  Tiles whose chroma keeps them inside it (tube_holds)
@@ -229,6 +230,11 @@ struct Planes2 {          // 32-bit strides: the launcher only sends layouts tha
 };
 
 // ---------------------------------------------------------------- variant traits
+// INTERP as a template argument: lut3d's modes 0 / 1 / 2, and T2_TET16 = tetrahedral on float4 nodes -- the strict kernels' whole-lattice
+// mode.  A tap is then one ds_read_b128 (4 LDS-array cycles) instead of ds_read2_b32 + ds_read_b32 (6), and scattered taps collide far
+// less: with the whole 17^3 lattice in LDS, uniform-random frames 351 -> 515 Gpx/s, sigma-64 noise 390 -> 524, sigma-16 +3 %, natural
+// frames the same (profiles/r03_exp35_whole_lattice_16byte_nodes.txt).  Everywhere else a third more nodes per KB is worth more (5.6).
+constexpr int T2_TET16 = 3;
 template <int INTERP, int V> struct Node {
     static constexpr bool fast = V == V_FAST;
     // bytes per node in a window: fast = four fp16 {r,g,b,-} (one ds_read_b64 per tap); strict 4-tap modes pack fp32 {r,g,b}
@@ -238,7 +244,7 @@ template <int INTERP, int V> struct Node {
     // 8 nodes.  (The strict kernels cannot afford it: fp32 records are 24 bytes, the tube would shrink to 4 cells and the windows to
     // nothing.)  The gather body rounds its differences to fp16 as well, so both paths compute the same number.
     static constexpr bool rec = LUTR_T2_TRIREC && fast && INTERP == LUTR_INTERP_TRILINEAR;
-    static constexpr int lds = fast ? (rec ? 12 : 8) : ((INTERP == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
+    static constexpr int lds = fast ? (rec ? 12 : 8) : ((INTERP == LUTR_INTERP_TRILINEAR || INTERP == T2_TET16 || LUTR_T2_NODE16) ? 16 : 12);
     static constexpr int glb = fast ? 8 : 16;                                              // bytes per node in HBM/L2
 };
 
@@ -925,7 +931,7 @@ DEV PxC px_finish(const LutConsts &L, const Win &W, const Crd &cr, const Crd &cg
     c.w01 = f2v{0.0f, 0.0f}; c.w23 = f2v{0.0f, 0.0f};
     if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
         c.w01.x = cr.d; c.w01.y = cg.d; c.w23.x = cb.d;
-    } else if constexpr (INTERP == LUTR_INTERP_TETRAHEDRAL) {
+    } else if constexpr (INTERP == LUTR_INTERP_TETRAHEDRAL || INTERP == T2_TET16) {
         // FFmpeg's six branches all evaluate (1-x) c000 + (x-y) cA + (y-z) cB + z c111 with (x,y,z) the fractions sorted
         // descending; ties only ever choose between taps whose weight is exactly 0 (finite lattice), so the sorted form is
         // bit-identical.
@@ -1481,7 +1487,7 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     }
     if (TG.whole) {
         // lattice layout of the global copy ((N+1)^3 nodes, blue fastest, index N replicates N-1): prev + 1 is always staged
-        W.o_r = N::lds * L.n1 * L.n1; W.o_g = N::lds * L.n1;
+        W.o_r = N::lds * TG.whole_a; W.o_g = N::lds * TG.whole_b;
         W.fr = (float)W.o_r; W.fg = (float)W.o_g; W.fb = (float)N::lds;
         W.fc = (float)(lds_base() + tab_bytes + kScratch);
     }
@@ -1557,17 +1563,18 @@ void k_yuv_tile2(LutConsts L_, YuvConsts K_, Planes2 P, FrameGeom G, Geom TG)
     if constexpr (V >= V_TAB) coord_table_fill<INTERP>(L, TG.tab_entries);     // the kernel's only barrier ...
     if (TG.whole) {                                                             // ... but for this one, in whole-lattice mode
         char *dst = smem + TG.tab_entries * 8 + kScratch;
-        const int nodes = L.n1 * L.n1 * L.n1;
+        const int nodes = L.n1 * L.n1 * L.n1, plane = L.n1 * L.n1;
         for (int i = threadIdx.x; i < nodes; i += 64 * LUTR_T2_WPB) {
+            const int r = i / plane, rem = i - r * plane, g = rem / L.n1, b = rem - g * L.n1;
+            const int o = r * TG.whole_a + g * TG.whole_b + b;                  // (padded strides: see whole_strides)
             if constexpr (N::rec) {
-                const int plane = L.n1 * L.n1;
                 const u3 rc = make_rec(L.lat16[i], L.lat16[i + plane < nodes ? i + plane : i]);
-                uint32_t *q = (uint32_t *)(dst + 12 * i); q[0] = rc.x; q[1] = rc.y; q[2] = rc.z;
-            } else if constexpr (N::fast) ((uint2 *)dst)[i] = L.lat16[i];
+                uint32_t *q = (uint32_t *)(dst + 12 * o); q[0] = rc.x; q[1] = rc.y; q[2] = rc.z;
+            } else if constexpr (N::fast) ((uint2 *)dst)[o] = L.lat16[i];
             else {
                 const float4 v = L.lat[i];
-                if constexpr (N::lds == 16) ((float4 *)dst)[i] = v;
-                else { float *q = (float *)(dst + 12 * i); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
+                if constexpr (N::lds == 16) ((float4 *)dst)[o] = v;
+                else { float *q = (float *)(dst + 12 * o); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
             }
         }
         __syncthreads();
@@ -1892,6 +1899,31 @@ struct Knob {
 #define T2_KNOB(NAME) ([]() -> const Knob & { static const Knob k(NAME); return k; }())
 }  // namespace
 
+// Whole-lattice mode: node (r, g, b) sits at index r * A + g * B + b.  With A = n1^2, B = n1 neighbouring cells collide in the LDS
+// banks for unlucky sizes (n1 = 20: A = 400 = 0 mod 16 -- every step along r lands in the same bank group of a ds_read_b128).  A few
+// nodes of padding per row and per plane remove that, as tube_plane_stride does for the tube.  Returns the bytes, or 0 if no layout fits.
+static long long whole_strides(int n1, int node, long long room, int *A, int *B)
+{
+    const int mod = node == 16 ? 16 : 32;
+    long long best_bytes = 0;
+    int best_bad = 1 << 30;
+    for (int pb = 0; pb < 4; pb++)
+        for (int pa = 0; pa < 16; pa++) {
+            const int b = n1 + pb, a = n1 * b + pa;
+            const long long bytes = (long long)n1 * a * node;
+            if (bytes > room) continue;
+            int bad = 0;
+            for (int dr = -2; dr <= 2; dr++)
+                for (int dg = -2; dg <= 2; dg++)
+                    for (int db = -2; db <= 2; db++) {
+                        if (!dr && !dg && !db) continue;
+                        if (((dr * a + dg * b + db) % mod + mod) % mod == 0) bad += (abs(dr) <= 1 && abs(dg) <= 1 && abs(db) <= 1) ? 100 : 1;
+                    }
+            if (bad < best_bad || (bad == best_bad && bytes < best_bytes)) { best_bad = bad; best_bytes = bytes; *A = a; *B = b; }
+        }
+    return best_bytes;
+}
+
 // The tube's chroma bound under a shared prelut (LutConsts::pre_shared).  FFmpeg resamples a cineSpace shaper WITHOUT normalising the
 // interpolation weight by the segment width (parse_cinespace: `mix = x - in_prelut[idx]`), so the curve lut3d applies is a staircase:
 // nearly flat inside a segment, a jump at every input point -- its largest step between two codes says nothing about the rise over
@@ -1982,13 +2014,28 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     tg.ch = ch; tg.nrc = (tg.nry + ch - 1) / ch; tg.nchunks = G.nframes * tg.nrc * tg.nsx;
     tg.tab_entries = vv >= V_TAB ? table_entries(K, din) : 0;
     tg.max_raw = (1 << din) - 1;
-    const int node = vv == V_FAST ? ((LUTR_T2_TRIREC && mode == LUTR_INTERP_TRILINEAR) ? 12 : 8)
-                                  : ((mode == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
+    const int node_ = vv == V_FAST ? ((LUTR_T2_TRIREC && mode == LUTR_INTERP_TRILINEAR) ? 12 : 8)
+                                   : ((mode == LUTR_INTERP_TRILINEAR || LUTR_T2_NODE16) ? 16 : 12);
     const int blocks_per_cu = waves_per_cu / LUTR_T2_WPB > 0 ? waves_per_cu / LUTR_T2_WPB : 1;
     const int lds_block = 163840 / blocks_per_cu - tg.tab_entries * 8 - t2::kScratch;
-    // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS
-    const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
-    tg.whole = (blocks_per_cu == 1 && !T2_KNOB("LUTR_NO_WHOLE") && whole_bytes <= lds_block) ? 1 : 0;
+    // whole-lattice mode: (N+1)^3 nodes behind the table in one workgroup's LDS, row and plane strides padded against bank conflicts.
+    // The strict tetrahedral kernels stage float4 nodes there when those fit too (T2_TET16; N <= 19 at 10 bit).
+    int node = node_;
+    long long whole_bytes = 0;
+    bool whole16 = false;
+    tg.whole = 0; tg.whole_a = L.n1 * L.n1; tg.whole_b = L.n1;
+    if (blocks_per_cu == 1 && !T2_KNOB("LUTR_NO_WHOLE")) {
+        if (node_ == 12 && mode == LUTR_INTERP_TETRAHEDRAL && vv != V_GEN && !T2_KNOB("LUTR_NO_WHOLE16")) {
+            int a, b;
+            const long long bytes = whole_strides(L.n1, 16, lds_block, &a, &b);
+            if (bytes) { tg.whole = 1; tg.whole_a = a; tg.whole_b = b; whole_bytes = bytes; whole16 = true; node = 16; }
+        }
+        if (!tg.whole) {
+            int a, b;
+            const long long bytes = whole_strides(L.n1, node_, lds_block, &a, &b);
+            if (bytes) { tg.whole = 1; tg.whole_a = a; tg.whole_b = b; whole_bytes = bytes; }
+        }
+    }
     // The grey tube (Geom::tube_h): all of r, |g - r| and |b - r| up to H cells.  Needs the table variants (equal channel scales: the
     // chroma-only bound of map_box), a blend (nearest rounds to a node, the bound is for floor), and room left for windows.
     // H: as wide as 70 % of the block's LDS allows while every wave keeps a window of 256 nodes, at most 8 cells of a 33^3 lattice
@@ -2090,6 +2137,11 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
 #define T2_NAME(WI, WO, X, Y, I, SUF) "k_yuv_tile2<" #WI #WO "," #X #Y "," #I SUF ">"
 #define T2_CASE(WI, WO, X, Y, I) \
     if (mode == I) { \
+        if (I == LUTR_INTERP_TETRAHEDRAL && whole16) {      /* (other I: the template argument falls back to an instance that exists anyway) */ \
+            if (pre) T2_LAUNCH(WI, WO, X, Y, (I == 2 ? T2_TET16 : 2), 1, V_UNIT, T2_NAME(WI, WO, X, Y, I, ",pre,tab,unit,n16")); \
+            if (vv == V_UNIT) T2_LAUNCH(WI, WO, X, Y, (I == 2 ? T2_TET16 : 2), 0, V_UNIT, T2_NAME(WI, WO, X, Y, I, ",tab,unit,n16")); \
+            if (vv == V_TAB) T2_LAUNCH(WI, WO, X, Y, (I == 2 ? T2_TET16 : 2), 0, V_TAB, T2_NAME(WI, WO, X, Y, I, ",tab,n16")); \
+        } \
         if (I != LUTR_INTERP_NEAREST) { \
             if (pre && vv == V_FAST) T2_LAUNCH(WI, WO, X, Y, (I == 0 ? 2 : I), 1, V_FAST, T2_NAME(WI, WO, X, Y, I, ",pre,tab,unit,fast")); \
             if (pre) T2_LAUNCH(WI, WO, X, Y, (I == 0 ? 2 : I), 1, V_UNIT, T2_NAME(WI, WO, X, Y, I, ",pre,tab,unit")); \

@@ -49,7 +49,7 @@ def main():
     t0, runs, px, tube_tiles, tiles, fast_runs, pre_runs = time.time(), 0, 0, 0, 0, 0, 0
     fmts = [("yuv420p10le", 10, 1, 1), ("yuv420p", 8, 1, 1), ("yuv422p10le", 10, 1, 0), ("yuv444p10le", 10, 0, 0), ("yuv444p", 8, 0, 0)]
     while time.time() - t0 < budget:
-        n = int(rng.choice([22, 26, 29, 33, 33, 33, 37, 40, 41, 65]))
+        n = int(rng.choice([9, 17, 19, 20, 21, 22, 26, 29, 33, 33, 33, 37, 40, 41, 65]))      # (up to 21 / 25: the whole lattice in LDS)
         lat = rng.uniform(0.0, 1.0, size=(n, n, n, 3)).astype(np.float32) if rng.random() < 0.3 else cube.log709_lattice(n)
         scale = np.array([1.0, 1.0, 1.0], np.float32) if rng.random() < 0.7 else np.full(3, rng.uniform(0.6, 1.0), np.float32)
         pre = None
