@@ -85,7 +85,8 @@ struct Geom {
     int nsx, nry, ch, nrc, nchunks;
     int tab_entries;      // per-code coordinate table at LDS offset 0 (0: coordinates are computed)
     int max_code;         // codes above it are illegal for the table (10- / 12-bit data in 16-bit containers)
-    int whole;            // the whole lattice is staged ((n+1)^3 nodes): no validity test
+    int whole;            // the whole lattice is staged ((n+1)^3 nodes): no validity test;
+    int whole_a, whole_b; //   node (r, g, b) at index r * whole_a + g * whole_b + b (strides padded against bank conflicts)
     int tube_h, tube_plane;
     int rev;              // memory order of the components is B, G, R: strides permuted, nodes staged with R and B swapped
     int three;            // three coordinate tables (one per channel: a prelut, or DOMAIN scales that differ), else one
@@ -240,8 +241,11 @@ struct Addr {
                                   // instead of 8 at 33^3): rgb24 608 vs 618, gbrp 646 vs 649, sigma-16 frames -5 % (profiles/r03_exp25): the
                                   // LDS is not what these kernels wait for
 #endif
+// INTERP as a template argument: lut3d's 0 / 1 / 2, and R2_TET16 = tetrahedral on float4 nodes, for the whole-lattice mode (one ds_read_b128
+// per tap, far fewer bank collisions between scattered taps; lutr_tile2.hip T2_TET16)
+constexpr int R2_TET16 = 3;
 template <int INTERP> struct NodeB {
-    static constexpr int lds = ((INTERP == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) || (INTERP != LUTR_INTERP_TRILINEAR && LUTR_R2_NODE16)) ? 16 : 12;
+    static constexpr int lds = ((INTERP == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) || INTERP == R2_TET16 || (INTERP != LUTR_INTERP_TRILINEAR && LUTR_R2_NODE16)) ? 16 : 12;
 };
 
 template <bool LDS, int NB> DEV f4 tap(const LutConsts &L, int a)
@@ -272,7 +276,7 @@ DEV Prep px_prep(const Addr &A, const Crd &q0, const Crd &q1, const Crd &q2)
     else c.a = (int)q0.p * A.o0 + (int)q1.p * A.o1 + (int)q2.p * A.o2;
     c.oa = c.oz = 0;
     c.w0 = q0.d; c.w1 = q1.d; c.w2 = q2.d; c.w3 = 0.0f;
-    if constexpr (INTERP == LUTR_INTERP_TETRAHEDRAL) {
+    if constexpr (INTERP == LUTR_INTERP_TETRAHEDRAL || INTERP == R2_TET16) {
         // the six branches of FFmpeg's tetrahedral form as (1-x) c000 + (x-y) cA + (y-z) cB + z c111 with the fractions sorted:
         // symmetric in the axes, ties only choose between taps of weight 0
         const float d0 = q0.d, d1 = q1.d, d2 = q2.d;
@@ -521,9 +525,12 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
         const int n1 = L.n1, nmax = L.n1 - 1;
         const int nodes = TG.whole ? n1 * n1 * n1 : n1 * TG.tube_plane;
         for (int i = threadIdx.x; i < nodes; i += 64 * LUTR_R2_WPB) {
-            int src;
-            if (TG.whole) src = i;
-            else {
+            int src, o = i;
+            if (TG.whole) {
+                src = i;
+                const int r = i / (n1 * n1), rem = i - r * n1 * n1, g = rem / n1;
+                o = r * TG.whole_a + g * TG.whole_b + (rem - g * n1);
+            } else {
                 // node (ir, ig, ib) = lattice (r, g = r + ig - H - 1, b = g + ib - H - 1), clamped (a clamped node is never read by a valid pixel)
                 const int ir = i / TG.tube_plane, rem = i - ir * TG.tube_plane, ig = min(rem / nb, nb - 1), ib = rem - ig * nb;
                 const int gq = ir + ig - TG.tube_h - 1;
@@ -532,8 +539,8 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
             }
             float4 v = L.lat[src];
             if (TG.rev) { const float t = v.x; v.x = v.z; v.z = t; }
-            if constexpr (NBL == 16) ((float4 *)dst)[i] = v;
-            else { float *q = (float *)(dst + 12 * i); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
+            if constexpr (NBL == 16) ((float4 *)dst)[o] = v;
+            else { float *q = (float *)(dst + 12 * o); q[0] = v.x; q[1] = v.y; q[2] = v.z; }
         }
     }
     __syncthreads();
@@ -541,7 +548,7 @@ void k_rgb_tube(LutConsts L, Planes P, FrameGeom G, Geom TG)
     Addr AL, AG;
     {
         int sr, sg, sb, base;       // node steps of r, g, b
-        if (TG.whole) { sr = L.n1 * L.n1; sg = L.n1; sb = 1; base = 0; }
+        if (TG.whole) { sr = TG.whole_a; sg = TG.whole_b; sb = 1; base = 0; }
         else { sr = TG.tube_plane - nb; sg = nb - 1; sb = 1; base = (TG.tube_h + 1) * nb + TG.tube_h + 1; }
         AL.o0 = NBL * (TG.rev ? sb : sr); AL.o1 = NBL * sg; AL.o2 = NBL * (TG.rev ? sr : sb);
         AL.f0 = (float)AL.o0; AL.f1 = (float)AL.o1; AL.f2 = (float)AL.o2;
@@ -704,6 +711,28 @@ int tube_plane_stride(int nb, int node)
     }
     return best;
 }
+// whole-lattice mode: row and plane strides of the (n+1)^3 copy, padded the same way (lutr_tile2.hip whole_strides); bytes, or 0 if none fits
+long long whole_strides(int n1, int node, long long room, int *A, int *B)
+{
+    const int mod = node == 16 ? 16 : 32;
+    long long best_bytes = 0;
+    int best_bad = 1 << 30;
+    for (int pb = 0; pb < 4; pb++)
+        for (int pa = 0; pa < 16; pa++) {
+            const int b = n1 + pb, a = n1 * b + pa;
+            const long long bytes = (long long)n1 * a * node;
+            if (bytes > room) continue;
+            int bad = 0;
+            for (int dr = -2; dr <= 2; dr++)
+                for (int dg = -2; dg <= 2; dg++)
+                    for (int db = -2; db <= 2; db++) {
+                        if (!dr && !dg && !db) continue;
+                        if (((dr * a + dg * b + db) % mod + mod) % mod == 0) bad += (abs(dr) <= 1 && abs(dg) <= 1 && abs(db) <= 1) ? 100 : 1;
+                    }
+            if (bad < best_bad || (bad == best_bad && bytes < best_bytes)) { best_bad = bad; best_bytes = bytes; *A = a; *B = b; }
+        }
+    return best_bytes;
+}
 // (17-node rows of 16-byte nodes collide on every g step whatever the plane stride; skipping H = 7 for H = 6 there measured WORSE --
 // gbrp trilinear 410 -> 379, rgb24 407 -> 369 Gpx/s: the wider tube is worth more than the conflicts cost)
 
@@ -763,10 +792,23 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.max_code = (1 << depth) - 1;
     tg.rev = rev;
     tg.three = three ? 1 : 0;
-    const int node = ((mode == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) || (mode != LUTR_INTERP_TRILINEAR && LUTR_R2_NODE16)) ? 16 : 12;
+    int node = ((mode == LUTR_INTERP_TRILINEAR && !LUTR_R2_TRI12) || (mode != LUTR_INTERP_TRILINEAR && LUTR_R2_NODE16)) ? 16 : 12;
     const long long room = 163840 - (long long)(three ? 3 : 1) * tg.tab_entries * 8 - r2::kWgq;
-    const long long whole_bytes = (long long)L.n1 * L.n1 * L.n1 * node;
-    tg.whole = whole_bytes <= room && !getenv("LUTR_NO_WHOLE");
+    // whole-lattice mode, strides padded; tetrahedral on float4 nodes when those fit too (R2_TET16)
+    long long whole_bytes = 0;
+    bool whole16 = false;
+    tg.whole = 0; tg.whole_a = L.n1 * L.n1; tg.whole_b = L.n1;
+    if (!getenv("LUTR_NO_WHOLE")) {
+        int a, b;
+        if (node == 12 && mode == LUTR_INTERP_TETRAHEDRAL && !getenv("LUTR_NO_WHOLE16")) {
+            const long long bytes = whole_strides(L.n1, 16, room, &a, &b);
+            if (bytes) { tg.whole = 1; tg.whole_a = a; tg.whole_b = b; whole_bytes = bytes; whole16 = true; node = 16; }
+        }
+        if (!tg.whole) {
+            const long long bytes = whole_strides(L.n1, node, room, &a, &b);
+            if (bytes) { tg.whole = 1; tg.whole_a = a; tg.whole_b = b; whole_bytes = bytes; }
+        }
+    }
     tg.tube_h = 0; tg.tube_plane = 0;
     long long lat_bytes = whole_bytes;
     if (!tg.whole) {
@@ -806,21 +848,21 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
 #define R2_STR_(x) #x
 #define R2_STR(x) R2_STR_(x)
 #define R2_NAME(I, SUF) "k_rgb_tube<ly" R2_STR(LUTR_R2_LAYOUT) "," #I SUF ">"
-#define R2_MODE(I) \
-    if (mode == I) { \
+#define R2_MODE_(I, K, SUF) \
         if (tab) { \
             if constexpr (LY != LY_C3W && LY != LY_C4W0 && LY != LY_C4W1) { \
-                if (three) R2_LAUNCH(I, 3, false, R2_NAME(I, ",tab3")); \
-                if (unit) R2_LAUNCH(I, 1, true, R2_NAME(I, ",tab,unit")); \
-                R2_LAUNCH(I, 1, false, R2_NAME(I, ",tab")); \
+                if (three) R2_LAUNCH(K, 3, false, R2_NAME(I, ",tab3" SUF)); \
+                if (unit) R2_LAUNCH(K, 1, true, R2_NAME(I, ",tab,unit" SUF)); \
+                R2_LAUNCH(K, 1, false, R2_NAME(I, ",tab" SUF)); \
             } \
         } else { \
             if constexpr (Y::WIDE) { \
-                if (unit) R2_LAUNCH(I, 0, true, R2_NAME(I, ",unit")); \
-                R2_LAUNCH(I, 0, false, R2_NAME(I, "")); \
+                if (unit) R2_LAUNCH(K, 0, true, R2_NAME(I, ",unit" SUF)); \
+                R2_LAUNCH(K, 0, false, R2_NAME(I, "" SUF)); \
             } \
-        } \
-    }
+        }
+#define R2_MODE(I) if (mode == I) { R2_MODE_(I, I, "") }
+    if (mode == LUTR_INTERP_TETRAHEDRAL && whole16) { R2_MODE_(2, R2_TET16, ",n16") }
     R2_MODE(0) R2_MODE(1) R2_MODE(2)
     return nullptr;
 }
