@@ -2042,7 +2042,7 @@ const char *T2_ENTRY(hipStream_t st, const LutConsts &L, const YuvConsts &K, con
     // (+-64 8-bit codes of G-R and B-R; 34 x 19 x 19 fp16 nodes = 98 KB, windows of 367 nodes).  Measured, UHD yuv420p10le fast,
     // H = 5 / 7 / 8 / 9: natural frames 611 / 620 / 628 / 636 Gpx/s, three times the chroma 516 / 521 / 530 / 519, sigma = 8 noise
     // 503 / 543 / 550 / 569, sigma = 16 250 / 388 / 481 / 500: the tube, not the windows, is what carries natural content; 9 leaves
-    // windows of 197 nodes and starts to cost saturated frames.  The strict kernels (12-byte nodes) get H = 6.
+    // windows of 197 nodes and starts to cost saturated frames.  The strict kernels (12-byte nodes) get H = 7 (below).
     tg.tube_h = 0; tg.tube_t = 0.0f; tg.tube_plane = 0;
     long long tube_bytes = 0;
     // (65^3: a tube that fits is 5 of ITS cells wide, +-20 8-bit codes -- 497 / 427 Gpx/s with it, 530 / 492 without: off above 40^3)
