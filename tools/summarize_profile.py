@@ -43,7 +43,7 @@ if summary.get("kernel_stats"):
     if cand:
         main = max(cand, key=lambda k: float(k["Calls"]) * float(k["AverageNs"]))["Name"].split("(")[0]
 summary["kernel_stats"] = [k for k in summary.get("kernel_stats", [])]
-for sub in ("fetch", "write", "sq", "tcc"):
+for sub in ("fetch", "write", "sq", "tcc", "gui"):
     for f in newest(str(src / sub / "*" / "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if "lutr::" in r["Kernel_Name"] and (main is None or r["Kernel_Name"].startswith(main)):
@@ -91,11 +91,18 @@ c = summary.get("counters_mean_per_dispatch") or {}
 if "bench" in summary and all(k in c for k in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES")) and c["SQ_WAVES"] > 0:
     px = summary["bench"]["value"] * 1e6 * summary["bench"]["ms_per_step"] * 1e-3
     cycles = 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]
+    # GRBM_GUI_ACTIVE (summed over the 8 XCDs) is the count the 2.5-cycle issue rate was calibrated in (tools/ubench/cycles.sh): use it
+    # when the run has it.  (SQ_WAVE_CYCLES x 4 / SQ_WAVES agrees with it at the product's 4 waves per SIMD, not at the 8 of the micro-benchmarks.)
+    cycles_sq = cycles
+    if "GRBM_GUI_ACTIVE" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0
     simds = 1024
     summary["valu_issue"] = {
         "valu_insts_per_px": round(c["SQ_INSTS_VALU"] * 64 / px, 1),
         "lds_insts_per_px": round(c.get("SQ_INSTS_LDS", 0) * 64 / px, 2),
         "shader_cycles_per_launch": round(cycles),
+        "cycles_source": "GRBM_GUI_ACTIVE / 8 XCDs" if "GRBM_GUI_ACTIVE" in c else "SQ_WAVE_CYCLES x 4 / SQ_WAVES",
+        "wave_lifetime_cycles_sq": round(cycles_sq),
         "shader_clock_GHz": round(cycles / (summary["kernel_time_us"]["mean_all"] * 1e3), 2) if "kernel_time_us" in summary else None,
         "cycles_per_valu_inst_at_best": 2.5,
         "frac_of_issue_limit": round(c["SQ_INSTS_VALU"] * 2.5 / (simds * cycles), 3),
