@@ -64,7 +64,7 @@
 #define LUTR_T2_PIN 2             // wave-uniform constants copied to VGPRs: 1-2 kernel-wide (Y rows), 3-4 per tile (window, chroma rows)
 #endif
 #ifndef LUTR_T2_PK
-#define LUTR_T2_PK 0              // 1: packed fp32 (v_pk_add/mul_f32) for the R,G pair of the strict blends, the luma add and the chroma
+#define LUTR_T2_PK 0              // bit mask (1: luma add of R,G; 2: blends; 4: * M; 8: chroma sums; 15 = round 2's "1"): packed fp32 (v_pk_add/mul_f32) for the R,G pair of the strict blends, the luma add and the chroma
                                   // sums -- bit-identical, 14 % fewer VALU instructions in the strict body (68.2 -> 58.7 per pixel), and
                                   // 1-2 % SLOWER: a packed op holds the fp32 pipe as long as the two scalar ops it replaces (4.6 vs 2 x 2.5 cycles)
 #endif
@@ -1075,7 +1075,7 @@ DEV Rgb3 px_blend(const LutConsts &L, const PxC &c, const Taps<LDS, INTERP, V> &
             v.r = T.t[0].x; v.g = T.t[0].y; v.b = T.t[0].z;
         } else if constexpr (INTERP == LUTR_INTERP_TRILINEAR) {
             const float dr = c.w01.x, dg = c.w01.y, db = c.w23.x;
-#if LUTR_T2_PK
+#if LUTR_T2_PK & 2
             // R and G ride in one register pair through FFmpeg's seven lerps (v0 + (v1 - v0) * f, each op rounded on its own, as
             // the scalar code below): 21 packed + 21 scalar instructions instead of 63
 #define XY(k) f2v{T.t[k].x, T.t[k].y}
@@ -1109,7 +1109,7 @@ DEV Rgb3 px_blend(const LutConsts &L, const PxC &c, const Taps<LDS, INTERP, V> &
 #endif
         } else {
             const float w0 = c.w01.x, w1 = c.w01.y, w2 = c.w23.x, w3 = c.w23.y;
-#if LUTR_T2_PK
+#if LUTR_T2_PK & 2
             // FFmpeg's w0 c000 + w1 cA + w2 cB + w3 c111, left to right, products and sums rounded one by one: R and G as a pair
             f2v rg = pk_mul_w<0>(f2v{T.t[0].x, T.t[0].y}, c.w01);
             rg = rg + pk_mul_w<1>(f2v{T.t[1].x, T.t[1].y}, c.w01);
@@ -1122,7 +1122,7 @@ DEV Rgb3 px_blend(const LutConsts &L, const PxC &c, const Taps<LDS, INTERP, V> &
 #endif
             v.b = w0 * T.t[0].z + w1 * T.t[1].z + w2 * T.t[2].z + w3 * T.t[3].z;
         }
-#if LUTR_T2_PK
+#if LUTR_T2_PK & 4
         if constexpr (INTERP != LUTR_INTERP_NEAREST) {
             const f2v rgm = pk_mul_lo(f2v{v.r, v.g}, L.maxf);
             v.r = rgm.x; v.g = rgm.y; v.b *= L.maxf;
@@ -1181,7 +1181,7 @@ DEV void group_coords(const LutConsts &L, const YuvConsts &K, const Geom &TG, co
         if constexpr (V >= V_TAB) {
             // clip(floor(v), 0, M): v_cvt_u32_f32 floors and saturates negatives to 0; the table is padded past M
             // K is the kernel's KB here: sums are 8 x the code, the masked conversion is the table's byte offset
-#if LUTR_T2_PK
+#if LUTR_T2_PK & 1
             const f2v rg = pk_add_lo(rgv[c], yy);  // {rv + yy, gv + yy}: the same two roundings as the scalar adds
             unsigned ri = (unsigned)rg.x & ~7u, gi = (unsigned)rg.y & ~7u, bi = (unsigned)(yy + bu[c]) & ~7u;
 #else
@@ -1282,13 +1282,13 @@ DEV void tile_body(const LutConsts &L, const YuvConsts &K_, const Win &W_, const
             for (int t = 0; t < TB; t++) o[qb + t] = px_quant<INTERP, V>(L, px_blend<LDS, INTERP, V>(L, pc[t], tp[t]));
         }
         float rs[NCG], gs[NCG], bs[NCG];
-#if LUTR_T2_PK
+#if LUTR_T2_PK & 8
         f2v rgs[NCG];               // chroma-block sums of R and G as a pair: one v_pk_add_f32 per pixel, same order of additions
 #endif
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int dy = p / GW, i = g * GW + p % GW, c = (p % GW) >> CSX;
-#if LUTR_T2_PK
+#if LUTR_T2_PK & 8
             const f2v orgp = {o[p].r, o[p].g};
             if (dy == 0 && ((p % GW) & (T::BW - 1)) == 0) { rgs[c] = orgp; bs[c] = o[p].b; }
             else { rgs[c] = rgs[c] + orgp; bs[c] += o[p].b; }
