@@ -43,6 +43,9 @@
                                   // output words (gbrp 605 vs 637, gbrp16le 383 vs 422 Gpx/s relative to the same reference kernel):
                                   // every write becomes a read-modify-write of a word whose other samples are still live input
 #endif
+#ifndef LUTR_R2_TB0
+#define LUTR_R2_TB0 1             // tap batch of the computed-coordinate instances: 1 pixel (no spill) or 2
+#endif
 #ifndef LUTR_R2_NT
 #define LUTR_R2_NT 1              // 1: non-temporal stores, 2: and loads
 #endif
@@ -368,7 +371,9 @@ DEV Acc tile_body(const LutConsts &L, const Addr &A, const Geom &TG, Unit<LY> &i
     // pixels whose coordinate reads are issued together: 4 where the registers allow (units of 8 words), else 2 -- a unit of 12
     // words in, 12 prefetched and 12 out leaves the tetrahedral body no room for 24 coordinates (one spilled register = scratch)
     constexpr int GP = ((!LUTR_R2_INPLACE && Y::NPL * Y::NW >= 12) || (INTERP == LUTR_INTERP_TRILINEAR && Y::NW >= 12) || Y::PX < 4) ? 2 : 4;
-    constexpr int TB = INTERP == LUTR_INTERP_TRILINEAR ? 1 : (INTERP == LUTR_INTERP_NEAREST ? GP : 2);   // pixels whose taps are in flight together
+    // pixels whose taps are in flight together (the instances that compute their coordinates -- 14- and 16-bit data -- spilled 3-6 registers
+    // to scratch with two)
+    constexpr int TB = INTERP == LUTR_INTERP_TRILINEAR ? 1 : (INTERP == LUTR_INTERP_NEAREST ? GP : ((TAB == 0 && LUTR_R2_TB0 == 1 && Y::NPL * Y::NW >= 12) ? 1 : 2));
 #pragma unroll
     for (int g = 0; g < Y::PX / GP; g++) {
         Crd q[GP][3];
@@ -800,7 +805,8 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
     tg.whole = 0; tg.whole_a = L.n1 * L.n1; tg.whole_b = L.n1;
     if (!getenv("LUTR_NO_WHOLE")) {
         int a, b;
-        if (node == 12 && mode == LUTR_INTERP_TETRAHEDRAL && !getenv("LUTR_NO_WHOLE16")) {
+        // (table variants only: the instances that compute their coordinates -- 14- and 16-bit data -- have no registers for float4 taps)
+        if (node == 12 && mode == LUTR_INTERP_TETRAHEDRAL && tab && !getenv("LUTR_NO_WHOLE16")) {
             const long long bytes = whole_strides(L.n1, 16, room, &a, &b);
             if (bytes) { tg.whole = 1; tg.whole_a = a; tg.whole_b = b; whole_bytes = bytes; whole16 = true; node = 16; }
         }
@@ -862,7 +868,13 @@ const char *R2_ENTRY(hipStream_t st, const LutConsts &L, const PlaneSet &P, cons
             } \
         }
 #define R2_MODE(I) if (mode == I) { R2_MODE_(I, I, "") }
-    if (mode == LUTR_INTERP_TETRAHEDRAL && whole16) { R2_MODE_(2, R2_TET16, ",n16") }
+    if (mode == LUTR_INTERP_TETRAHEDRAL && whole16) {
+        if constexpr (LY != LY_C3W && LY != LY_C4W0 && LY != LY_C4W1) {
+            if (three) R2_LAUNCH(R2_TET16, 3, false, R2_NAME(2, ",tab3,n16"));
+            if (unit) R2_LAUNCH(R2_TET16, 1, true, R2_NAME(2, ",tab,unit,n16"));
+            R2_LAUNCH(R2_TET16, 1, false, R2_NAME(2, ",tab,n16"));
+        }
+    }
     R2_MODE(0) R2_MODE(1) R2_MODE(2)
     return nullptr;
 }
